@@ -1,0 +1,153 @@
+/*
+ * hmo.h -- ORACLE (test infrastructure, NOT the product path).
+ *
+ * Plain-C CPU restatement of the HM-16.3 all-intra CU depth/mode RDO decision loop
+ * (TEncCu::compressCtu + TEncCu::encodeCtu context replay) as found in
+ * Jiraiya812/Fast-CU-Decision-HEVC, with the fork's state fixed to "Training"
+ * (exhaustive HM RDO).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
+ * code.  The HIP product path never links or calls it.
+ *
+ * Parity status: see oracle/README.md ("pinning").
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference).
+ */
+#ifndef HMO_H
+#define HMO_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fixed coding structure (encoder_intra_main.cfg) ---------------- */
+#define HMO_CTU          64     /* MaxCUWidth/Height                                  */
+#define HMO_MAXDEPTH     3      /* CU depths 0..3 (64,32,16,8); g_uiMaxCUDepth-g_uiAddCUDepth */
+#define HMO_NPART        256    /* 4x4 partitions per CTU (z-order)                   */
+#define HMO_LOG2_MAXTU   5      /* QuadtreeTULog2MaxSize                              */
+#define HMO_LOG2_MINTU   2      /* QuadtreeTULog2MinSize                              */
+#define HMO_TU_MAXDEPTH_INTRA 3 /* QuadtreeTUMaxDepthIntra                            */
+
+/* enums as TypeDef.h:470-489 */
+#define HMO_SIZE_2Nx2N   0
+#define HMO_SIZE_NxN     3
+#define HMO_SIZE_NONE    8      /* NUMBER_OF_PART_SIZES */
+#define HMO_MODE_INTER   0
+#define HMO_MODE_INTRA   1
+#define HMO_MODE_NONE    2      /* NUMBER_OF_PREDICTION_MODES */
+#define HMO_PLANAR 0
+#define HMO_DC     1
+#define HMO_HOR    10
+#define HMO_VER    26
+#define HMO_DM_CHROMA 36
+
+/* CABAC context layout (own numbering; counts from ContextTables.h:49-161) */
+enum {
+  HMO_CTX_SPLIT      = 0,    /* 3  */
+  HMO_CTX_PARTSIZE   = 3,    /* 1  (ctx 0 of 4; intra only uses the first) */
+  HMO_CTX_INTRA_LUMA = 4,    /* 1  prev_intra_luma_pred_flag */
+  HMO_CTX_CHROMA_PRED= 5,    /* 1  */
+  HMO_CTX_CBF_LUMA   = 6,    /* 5  */
+  HMO_CTX_CBF_CHROMA = 11,   /* 5  */
+  HMO_CTX_SUBDIV     = 16,   /* 3  */
+  HMO_CTX_SIGCG      = 19,   /* 2 luma + 2 chroma */
+  HMO_CTX_SIG        = 23,   /* 28 luma + 16 chroma */
+  HMO_CTX_LASTX      = 67,   /* 15 luma + 15 chroma */
+  HMO_CTX_LASTY      = 97,   /* 15 luma + 15 chroma */
+  HMO_CTX_ONE        = 127,  /* 16 luma + 8 chroma */
+  HMO_CTX_ABS        = 151,  /* 4 luma + 2 chroma */
+  HMO_CTX_TSKIP      = 157,  /* 1 luma + 1 chroma */
+  HMO_NCTX           = 160
+};
+
+/* coder state that HM copies with TEncSbac::load/store (TEncSbac.cpp:397-426,
+ * TEncBinCoderCABAC.cpp:148-159): all context states + the fractional bit counter. */
+typedef struct {
+  uint8_t  ctx[HMO_NCTX];
+  uint64_t frac;             /* m_fracBits (Q15) */
+} HmoCabac;
+
+/* slots per depth, TypeDef.h:554-563 */
+enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
+
+/* Encoder parameters for one chain (= one slice sequence of one frame). */
+typedef struct {
+  int width, height;            /* luma samples */
+  int qp;                       /* slice QP */
+  int slice_ctus;               /* SliceMode 1 / SliceArgument; 0 = whole frame is one slice */
+  int transform_skip;           /* TransformSkip (1) */
+  int transform_skip_fast;      /* TransformSkipFast (1) */
+  int sign_hiding;              /* SignHideFlag (1) */
+  int strong_smoothing;         /* StrongIntraSmoothing (1) */
+  /* derived by hmo_params_finish(): */
+  double lambda;                /* TComRdCost::m_dLambda             TEncSlice.cpp:686-706 */
+  double sqrt_lambda;           /* TComRdCost::m_sqrtLambda          TComRdCost.cpp:197    */
+  double chroma_weight;         /* m_distortionWeight[Cb/Cr]         TEncSlice.cpp:510     */
+  double rdoq_lambda[3];        /* TComTrQuant::m_lambdas            TEncSlice.cpp:512     */
+  int    qp_c;                  /* chroma QP (g_aucChromaScale)                             */
+} HmoParams;
+
+/* Per-CTU decisions, TComDataCU layout (TComDataCU.h:72-164).  One entry
+ * per 4x4 luma partition in z-order. */
+typedef struct {
+  uint8_t  depth[HMO_NPART], width[HMO_NPART], height[HMO_NPART];
+  uint8_t  skip[HMO_NPART];
+  int8_t   part_size[HMO_NPART], pred_mode[HMO_NPART];
+  uint8_t  tq_bypass[HMO_NPART];
+  int8_t   qp[HMO_NPART];
+  uint8_t  chroma_qp_adj[HMO_NPART];
+  uint8_t  tr_idx[HMO_NPART];
+  uint8_t  tskip[3][HMO_NPART];
+  uint8_t  cbf[3][HMO_NPART];
+  uint8_t  intra_dir[2][HMO_NPART];
+  uint8_t  ipcm[HMO_NPART];
+  int32_t  coeff_y[HMO_CTU * HMO_CTU];          /* TU-contiguous, offset = absPartIdx*16 */
+  int32_t  coeff_cb[HMO_CTU * HMO_CTU / 4];
+  int32_t  coeff_cr[HMO_CTU * HMO_CTU / 4];
+  double   total_cost;
+  uint32_t total_dist, total_bits, total_bins;
+} HmoCtu;
+
+typedef struct HmoEnc HmoEnc;
+
+/* ---- public oracle API ------------------------------------------------------------ */
+void    hmo_params_default(HmoParams *p, int width, int height, int qp);
+void    hmo_params_finish(HmoParams *p);
+HmoEnc *hmo_create(const HmoParams *p);
+void    hmo_destroy(HmoEnc *e);
+/* planes: 8-bit 4:2:0.  rec planes are written (picture-sized, stride = plane width). */
+void    hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const uint8_t *orgV,
+                       uint8_t *recY, uint8_t *recU, uint8_t *recV);
+/* compressCtu + encodeCtu replay for CTU ctuRsAddr (must be called in raster order). */
+void    hmo_compress_ctu(HmoEnc *e, int ctuRsAddr);
+const HmoCtu *hmo_get_ctu(const HmoEnc *e, int ctuRsAddr);
+/* CABAC state of m_pppcRDSbacCoder[0][CI_CURR_BEST] after the last encodeCtu. */
+const HmoCabac *hmo_get_cabac(const HmoEnc *e);
+/* whole frame */
+void    hmo_compress_frame(HmoEnc *e);
+int     hmo_num_ctus(const HmoEnc *e);
+uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int ctuRsAddr);
+
+/* ---- leaf functions exported for known-answer tests -------------------------------- */
+void    hmo_fwd_transform(const int16_t *resi, int stride, int32_t *coef, int log2, int useDst);
+void    hmo_inv_transform(const int32_t *coef, int16_t *resi, int stride, int log2, int useDst);
+uint32_t hmo_satd(const uint8_t *org, int so, const uint8_t *pred, int sp, int w, int h);
+uint32_t hmo_sse(const uint8_t *org, int so, const uint8_t *rec, int sr, int w, int h);
+/* intra prediction from a linear reference array ref[0..4N] (bottom-left .. corner .. top-right) */
+void    hmo_intra_pred(const uint8_t *ref, const uint8_t *refFilt, int log2, int mode, int isLuma,
+                       uint8_t *dst, int dstStride);
+void    hmo_filter_ref(const uint8_t *ref, uint8_t *out, int n, int strong);
+int     hmo_use_filtered_ref(int mode, int log2, int isLuma);
+void    hmo_cabac_init(HmoCabac *c, int qp);
+const int16_t *hmo_dct_matrix(int log2);   /* N*N, row-major */
+const uint16_t *hmo_scan(int scanType, int log2);
+const uint8_t *hmo_zscan_to_raster(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

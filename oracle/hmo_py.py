@@ -1,0 +1,104 @@
+"""ctypes binding of the ORACLE (oracle/libhmo.so).  Test infrastructure only: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NPART = 256
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("qp", C.c_int), ("slice_ctus", C.c_int),
+                ("transform_skip", C.c_int), ("transform_skip_fast", C.c_int), ("sign_hiding", C.c_int),
+                ("strong_smoothing", C.c_int), ("lambda_", C.c_double), ("sqrt_lambda", C.c_double),
+                ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int)]
+
+
+class Ctu(C.Structure):
+    _fields_ = [("depth", C.c_uint8 * NPART), ("width", C.c_uint8 * NPART), ("height", C.c_uint8 * NPART),
+                ("skip", C.c_uint8 * NPART), ("part_size", C.c_int8 * NPART), ("pred_mode", C.c_int8 * NPART),
+                ("tq_bypass", C.c_uint8 * NPART), ("qp", C.c_int8 * NPART), ("chroma_qp_adj", C.c_uint8 * NPART),
+                ("tr_idx", C.c_uint8 * NPART), ("tskip", (C.c_uint8 * NPART) * 3), ("cbf", (C.c_uint8 * NPART) * 3),
+                ("intra_dir", (C.c_uint8 * NPART) * 2), ("ipcm", C.c_uint8 * NPART),
+                ("coeff_y", C.c_int32 * 4096), ("coeff_cb", C.c_int32 * 1024), ("coeff_cr", C.c_int32 * 1024),
+                ("total_cost", C.c_double), ("total_dist", C.c_uint32), ("total_bits", C.c_uint32),
+                ("total_bins", C.c_uint32)]
+
+
+class Cabac(C.Structure):
+    _fields_ = [("ctx", C.c_uint8 * 160), ("frac", C.c_uint64)]
+
+
+def load():
+    lib = C.CDLL(os.path.join(_HERE, "libhmo.so"))
+    lib.hmo_create.restype = C.c_void_p
+    lib.hmo_create.argtypes = [C.POINTER(Params)]
+    lib.hmo_destroy.argtypes = [C.c_void_p]
+    lib.hmo_params_default.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+    lib.hmo_params_finish.argtypes = [C.POINTER(Params)]
+    lib.hmo_set_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.hmo_compress_ctu.argtypes = [C.c_void_p, C.c_int]
+    lib.hmo_compress_frame.argtypes = [C.c_void_p]
+    lib.hmo_get_ctu.restype = C.POINTER(Ctu)
+    lib.hmo_get_ctu.argtypes = [C.c_void_p, C.c_int]
+    lib.hmo_get_cabac.restype = C.POINTER(Cabac)
+    lib.hmo_get_cabac.argtypes = [C.c_void_p]
+    lib.hmo_num_ctus.argtypes = [C.c_void_p]
+    lib.hmo_ctu_replay_bits.restype = C.c_uint32
+    lib.hmo_ctu_replay_bits.argtypes = [C.c_void_p, C.c_int]
+    return lib
+
+
+class Encoder:
+    """One chain: a frame (or its slices) decided CTU by CTU in raster order."""
+
+    def __init__(self, Y, U, V, qp, slice_ctus=0, **flags):
+        self.lib = load()
+        h, w = Y.shape
+        self.p = Params()
+        self.lib.hmo_params_default(C.byref(self.p), w, h, qp)
+        self.p.slice_ctus = slice_ctus
+        for k, v in flags.items():
+            setattr(self.p, k, v)
+        self.lib.hmo_params_finish(C.byref(self.p))
+        self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
+        self.rec = [np.zeros_like(a) for a in self.org]
+        self.h = self.lib.hmo_create(C.byref(self.p))
+        self.lib.hmo_set_planes(self.h, *[a.ctypes.data for a in self.org], *[a.ctypes.data for a in self.rec])
+        self.n_ctu = self.lib.hmo_num_ctus(self.h)
+
+    def compress_ctu(self, a):
+        self.lib.hmo_compress_ctu(self.h, a)
+
+    def compress_frame(self):
+        self.lib.hmo_compress_frame(self.h)
+
+    def ctu(self, a):
+        return self.lib.hmo_get_ctu(self.h, a).contents
+
+    def ctu_arrays(self, a):
+        c = self.ctu(a)
+        out = {}
+        for name, _ in Ctu._fields_:
+            v = getattr(c, name)
+            out[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
+        return out
+
+    def cabac(self):
+        c = self.lib.hmo_get_cabac(self.h).contents
+        return np.ctypeslib.as_array(c.ctx).copy(), int(c.frac)
+
+    def replay_bits(self, a):
+        return self.lib.hmo_ctu_replay_bits(self.h, a)
+
+    def close(self):
+        if self.h:
+            self.lib.hmo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,968 @@
+/*
+ * hmo_search.c -- ORACLE (test infrastructure).  The CU / PU / TU decision loops:
+ * TEncCu::xCompressCU, xCheckRDCostIntra, TEncSearch::estIntraPredLumaQT / ChromaQT,
+ * xRecurIntraCodingLumaQT, xRecurIntraChromaCodingQT, and the encodeCtu context replay.
+ */
+#include "hmo_int.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------------------------
+ * geometry helpers
+ * ---------------------------------------------------------------------------------- */
+static inline int part_x(int z) { return (hmo_z2r[z] & 15) << 2; }      /* g_auiRasterToPelX[g_auiZscanToRaster[z]] */
+static inline int part_y(int z) { return (hmo_z2r[z] >> 4) << 2; }
+static inline int cu_size(const HmoCU *cu) { return HMO_CTU >> cu->depth_cu; }
+static inline int ctu_of(const HmoEnc *e, int lx, int ly) { return (ly >> 6) * e->w_ctu + (lx >> 6); }
+static inline int zidx_of(int lx, int ly) { return hmo_r2z[((ly & 63) >> 2) * 16 + ((lx & 63) >> 2)]; }
+static inline int inside_cu(const HmoCU *cu, int lx, int ly)
+{ int s = cu_size(cu); return lx >= cu->x && lx < cu->x + s && ly >= cu->y && ly < cu->y + s; }
+
+/* double floor(D + R*lambda + 0.5): TComRdCost::calcRdCost, TComRdCost.cpp:56-123 */
+static double calc_rd_cost(const HmoEnc *e, uint32_t bits, uint32_t dist)
+{ return floor((double)dist + ((double)bits * e->p.lambda) + 0.5); }
+
+/* ------------------------------------------------------------------------------------
+ * TU descriptors (TComTU.cpp:47-207)
+ * ---------------------------------------------------------------------------------- */
+static void tu_root(HmoTU *t, const HmoCU *cu)
+{
+  int s = cu_size(cu);
+  memset(t, 0, sizeof(*t));
+  t->log2 = 6 - cu->depth_cu; t->tr_depth = 0; t->part = 0; t->nparts = cu->nparts;
+  t->cw = t->cwo = s >> 1; t->c_tr_depth = 0; t->c_code_all = 1;
+}
+/* TComTURecurse(parent, bProcessLastOfLevel, QUAD_SPLIT) advanced to section `i` */
+static void tu_child(HmoTU *c, const HmoTU *p, int i, int processLast)
+{
+  int s = 1 << (p->log2 - 1);
+  c->log2 = p->log2 - 1; c->tr_depth = p->tr_depth + 1;
+  c->nparts = p->nparts >> 2; if (c->nparts < 1) c->nparts = 1;
+  c->part = p->part + i * c->nparts;
+  c->x = p->x + (i & 1) * s; c->y = p->y + (i >> 1) * s;
+  c->off_y = p->off_y + i * s * s;
+  c->section = i;
+  int pw = p->cwo;                                     /* parent's full chroma rect width */
+  if ((pw >> 1) >= 4) {
+    int cs = pw >> 1;
+    c->cw = c->cwo = cs; c->c_code_all = 1; c->c_tr_depth = p->c_tr_depth + 1;
+    c->cx = p->cx + (i & 1) * cs; c->cy = p->cy + (i >> 1) * cs;
+    c->off_c = p->off_c + i * cs * cs;
+  } else {                                             /* 2x2 would be too small: stay at parent's 4x4 */
+    c->cwo = pw; c->c_code_all = 0; c->c_tr_depth = p->c_tr_depth;
+    c->cx = p->cx; c->cy = p->cy; c->off_c = p->off_c;
+    c->cw = (processLast ? (i == 3) : (i == 0)) ? pw : 0;
+  }
+}
+static inline int tu_part_c(const HmoTU *t) { return t->c_code_all ? t->part : (t->part & ~3); }        /* GetAbsPartIdxTU(chroma) */
+static inline int tu_nparts_c(const HmoTU *t) { return t->c_code_all ? t->nparts : t->nparts * 4; }      /* GetAbsPartIdxNumParts(chroma) */
+
+/* ------------------------------------------------------------------------------------
+ * CU object helpers (TComDataCU.cpp:592-1065)
+ * ---------------------------------------------------------------------------------- */
+/* initEstData / initSubCU */
+static void cu_init(HmoCU *cu, int depth, int x, int y, int zidx)
+{
+  cu->depth_cu = depth; cu->x = x; cu->y = y; cu->zidx = zidx; cu->nparts = HMO_NPART >> (2 * depth);
+  cu->cost = HMO_MAX_DOUBLE; cu->dist = 0; cu->bits = 0; cu->bins = 0;
+  int n = cu->nparts;
+  memset(cu->depth, depth, (size_t)n);
+  memset(cu->part_size, HMO_SIZE_NONE, (size_t)n);
+  memset(cu->pred_mode, HMO_MODE_NONE, (size_t)n);
+  memset(cu->tr_idx, 0, (size_t)n);
+  for (int c = 0; c < 3; c++) { memset(cu->tskip[c], 0, (size_t)n); memset(cu->cbf[c], 0, (size_t)n); }
+  memset(cu->intra_dir[0], HMO_DC, (size_t)n);
+  memset(cu->intra_dir[1], 0, (size_t)n);
+  int s = HMO_CTU >> depth;
+  memset(cu->coef[0], 0, sizeof(int32_t) * (size_t)(s * s));
+  memset(cu->coef[1], 0, sizeof(int32_t) * (size_t)(s * s / 4));
+  memset(cu->coef[2], 0, sizeof(int32_t) * (size_t)(s * s / 4));
+}
+/* copyPartFrom, TComDataCU.cpp:906-990 */
+static void cu_copy_part_from(HmoCU *dst, const HmoCU *src, int partUnitIdx)
+{
+  int n = src->nparts, off = partUnitIdx * n;
+  dst->dist += src->dist; dst->bits += src->bits; dst->bins += src->bins;
+  memcpy(dst->depth + off, src->depth, (size_t)n);
+  memcpy(dst->part_size + off, src->part_size, (size_t)n);
+  memcpy(dst->pred_mode + off, src->pred_mode, (size_t)n);
+  memcpy(dst->tr_idx + off, src->tr_idx, (size_t)n);
+  for (int c = 0; c < 3; c++) { memcpy(dst->tskip[c] + off, src->tskip[c], (size_t)n); memcpy(dst->cbf[c] + off, src->cbf[c], (size_t)n); }
+  memcpy(dst->intra_dir[0] + off, src->intra_dir[0], (size_t)n);
+  memcpy(dst->intra_dir[1] + off, src->intra_dir[1], (size_t)n);
+  memcpy(dst->coef[0] + off * 16, src->coef[0], sizeof(int32_t) * (size_t)(n * 16));
+  memcpy(dst->coef[1] + off * 4, src->coef[1], sizeof(int32_t) * (size_t)(n * 4));
+  memcpy(dst->coef[2] + off * 4, src->coef[2], sizeof(int32_t) * (size_t)(n * 4));
+}
+/* copyToPic, TComDataCU.cpp:992-1065 */
+static void cu_copy_to_pic(HmoEnc *e, const HmoCU *cu)
+{
+  HmoCtu *p = &e->pic[e->cur_ctu];
+  int n = cu->nparts, off = cu->zidx, s = cu_size(cu);
+  p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins;
+  memcpy(p->depth + off, cu->depth, (size_t)n);
+  memset(p->width + off, s, (size_t)n); memset(p->height + off, s, (size_t)n);
+  memset(p->skip + off, 0, (size_t)n);
+  memcpy(p->part_size + off, cu->part_size, (size_t)n);
+  memcpy(p->pred_mode + off, cu->pred_mode, (size_t)n);
+  memset(p->qp + off, e->p.qp, (size_t)n);
+  memcpy(p->tr_idx + off, cu->tr_idx, (size_t)n);
+  for (int c = 0; c < 3; c++) { memcpy(p->tskip[c] + off, cu->tskip[c], (size_t)n); memcpy(p->cbf[c] + off, cu->cbf[c], (size_t)n); }
+  memcpy(p->intra_dir[0] + off, cu->intra_dir[0], (size_t)n);
+  memcpy(p->intra_dir[1] + off, cu->intra_dir[1], (size_t)n);
+  memcpy(p->coeff_y + off * 16, cu->coef[0], sizeof(int32_t) * (size_t)(n * 16));
+  memcpy(p->coeff_cb + off * 4, cu->coef[1], sizeof(int32_t) * (size_t)(n * 4));
+  memcpy(p->coeff_cr + off * 4, cu->coef[2], sizeof(int32_t) * (size_t)(n * 4));
+}
+
+/* neighbour field access: inside the working CU -> its arrays, else the committed picture
+ * data (getPULeft/getPUAbove returning `this` vs. getPic()->getCtu(), TComDataCU.cpp:1071-1140) */
+static int nb_depth(const HmoEnc *e, const HmoCU *cu, int lx, int ly)
+{ return inside_cu(cu, lx, ly) ? cu->depth[zidx_of(lx, ly) - cu->zidx] : e->pic[ctu_of(e, lx, ly)].depth[zidx_of(lx, ly)]; }
+static int nb_luma_dir(const HmoEnc *e, const HmoCU *cu, int lx, int ly)
+{
+  if (inside_cu(cu, lx, ly)) { int p = zidx_of(lx, ly) - cu->zidx; return cu->pred_mode[p] == HMO_MODE_INTRA ? cu->intra_dir[0][p] : HMO_DC; }
+  const HmoCtu *c = &e->pic[ctu_of(e, lx, ly)]; int p = zidx_of(lx, ly);
+  return c->pred_mode[p] == HMO_MODE_INTRA ? c->intra_dir[0][p] : HMO_DC;
+}
+static int left_ctu_ok(const HmoEnc *e, int lx, int ly)     /* slice restriction of getPULeft */
+{ if (lx == 0) return 0; if (lx & 63) return 1; return ctu_of(e, lx, ly) - 1 >= e->slice_start; }
+static int above_ctu_ok(const HmoEnc *e, int lx, int ly)
+{ if (ly == 0) return 0; if (ly & 63) return 1; return ctu_of(e, lx, ly) - e->w_ctu >= e->slice_start; }
+
+/* TComDataCU::getIntraDirPredictor, TComDataCU.cpp:1542-1624 (luma) ; returns *piMode */
+static int intra_dir_predictor(const HmoEnc *e, const HmoCU *cu, int part, int preds[3])
+{
+  int z = cu->zidx + part;
+  int lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
+  int left = left_ctu_ok(e, lx, ly) ? nb_luma_dir(e, cu, lx - 1, ly) : HMO_DC;
+  int above = ((ly & 63) != 0) ? nb_luma_dir(e, cu, lx, ly - 1) : HMO_DC;   /* planarAtCtuBoundary */
+  if (left == above) {
+    if (left > 1) { preds[0] = left; preds[1] = ((left + 29) % 32) + 2; preds[2] = ((left - 1) % 32) + 2; }
+    else { preds[0] = HMO_PLANAR; preds[1] = HMO_DC; preds[2] = HMO_VER; }
+    return 1;
+  }
+  preds[0] = left; preds[1] = above;
+  if (left && above) preds[2] = HMO_PLANAR;
+  else preds[2] = (left + above) < 2 ? HMO_VER : HMO_DC;
+  return 2;
+}
+
+/* ------------------------------------------------------------------------------------
+ * syntax elements (TEncSbac.cpp)
+ * ---------------------------------------------------------------------------------- */
+/* codeSplitFlag, TEncSbac.cpp:613-628 + getCtxSplitFlag, TComDataCU.cpp:1626-1640 */
+static void code_split_flag(HmoEnc *e, const HmoCU *cu, int part, int depth)
+{
+  if (depth == HMO_MAXDEPTH) return;
+  int z = cu->zidx + part;
+  int lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
+  int ctx = 0;
+  if (left_ctu_ok(e, lx, ly)) ctx += nb_depth(e, cu, lx - 1, ly) > depth;
+  if (above_ctu_ok(e, lx, ly)) ctx += nb_depth(e, cu, lx, ly - 1) > depth;
+  hmo_enc_bin(e, cu->depth[part] > depth, HMO_CTX_SPLIT + ctx);
+}
+/* codePartSize (intra), TEncSbac.cpp:436-448 */
+static void code_part_size(HmoEnc *e, const HmoCU *cu, int part, int depth)
+{ if (depth == HMO_MAXDEPTH) hmo_enc_bin(e, cu->part_size[part] == HMO_SIZE_2Nx2N, HMO_CTX_PARTSIZE); }
+/* codeIntraDirLumaAng, TEncSbac.cpp:643-696 */
+static void code_intra_dir_luma(HmoEnc *e, const HmoCU *cu, int part, int multiple)
+{
+  int dir[4], preds[4][3], predIdx[4];
+  int partNum = multiple ? (cu->part_size[part] == HMO_SIZE_NxN ? 4 : 1) : 1;
+  int partOffset = (HMO_NPART >> (cu->depth[part] << 1)) >> 2;
+  for (int j = 0; j < partNum; j++) {
+    dir[j] = cu->intra_dir[0][part + partOffset * j];
+    intra_dir_predictor(e, cu, part + partOffset * j, preds[j]);
+    predIdx[j] = -1;
+    for (int i = 0; i < 3; i++) if (dir[j] == preds[j][i]) predIdx[j] = i;
+    hmo_enc_bin(e, predIdx[j] != -1, HMO_CTX_INTRA_LUMA);
+  }
+  for (int j = 0; j < partNum; j++) {
+    if (predIdx[j] != -1) hmo_enc_bins_ep(e, predIdx[j] ? 2 : 1);
+    else hmo_enc_bins_ep(e, 5);
+  }
+}
+/* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
+static void allowed_chroma_dir(const HmoCU *cu, int part, int list[5])
+{
+  list[0] = HMO_PLANAR; list[1] = HMO_VER; list[2] = HMO_HOR; list[3] = HMO_DC; list[4] = HMO_DM_CHROMA;
+  int luma = cu->intra_dir[0][part];
+  for (int i = 0; i < 4; i++) if (luma == list[i]) { list[i] = 34; break; }
+}
+/* codeIntraDirChroma, TEncSbac.cpp:698-725 */
+static void code_intra_dir_chroma(HmoEnc *e, const HmoCU *cu, int part)
+{
+  if (cu->intra_dir[1][part] == HMO_DM_CHROMA) hmo_enc_bin(e, 0, HMO_CTX_CHROMA_PRED);
+  else { hmo_enc_bin(e, 1, HMO_CTX_CHROMA_PRED); hmo_enc_bins_ep(e, 2); }
+}
+/* codeQtCbf, TEncSbac.cpp:920-995 (square 4:2:0 blocks only) + getCtxQtCbf TComDataCU.cpp:1642-1656 */
+static void code_qt_cbf(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp, int lowestLevel)
+{
+  if (comp == 0) {
+    hmo_enc_bin(e, (cu->cbf[0][tu->part] >> tu->tr_depth) & 1, HMO_CTX_CBF_LUMA + (tu->tr_depth == 0 ? 1 : 0));
+  } else {
+    int canQuadSplit = tu->cw >= 8;
+    int lowestDepth = tu->tr_depth + ((!lowestLevel && !canQuadSplit) ? 1 : 0);
+    hmo_enc_bin(e, (cu->cbf[comp][tu_part_c(tu)] >> lowestDepth) & 1, HMO_CTX_CBF_CHROMA + tu->tr_depth);
+  }
+}
+static int min_tu_log2_in_cu(const HmoCU *cu, int part)       /* getQuadtreeTULog2MinSizeInCU, TComDataCU.cpp:1658-1686 */
+{
+  int log2Cb = 6 - cu->depth[part];
+  int split = cu->part_size[part] == HMO_SIZE_NxN;
+  if (log2Cb < HMO_LOG2_MINTU + HMO_TU_MAXDEPTH_INTRA - 1 + split) return HMO_LOG2_MINTU;
+  int m = log2Cb - (HMO_TU_MAXDEPTH_INTRA - 1 + split);
+  return m > HMO_LOG2_MAXTU ? HMO_LOG2_MAXTU : m;
+}
+
+/* ------------------------------------------------------------------------------------
+ * search-time bit counting (TEncSearch.cpp:866-1090)
+ * ---------------------------------------------------------------------------------- */
+/* xEncSubdivCbfQT */
+static void enc_subdiv_cbf_qt(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int bLuma, int bChroma)
+{
+  int subdiv = cu->tr_idx[tu->part] > tu->tr_depth;
+  if (cu->part_size[0] == HMO_SIZE_NxN && tu->tr_depth == 0) { /* inferred */ }
+  else if (tu->log2 > HMO_LOG2_MAXTU) { }
+  else if (tu->log2 == HMO_LOG2_MINTU) { }
+  else if (tu->log2 == min_tu_log2_in_cu(cu, tu->part)) { }
+  else if (bLuma) hmo_enc_bin(e, subdiv, HMO_CTX_SUBDIV + 5 - tu->log2);
+  if (bChroma) {
+    for (int comp = 1; comp < 3; comp++)
+      if (tu->c_code_all && (tu->tr_depth == 0 || ((cu->cbf[comp][tu->part] >> (tu->tr_depth - 1)) & 1)))
+        code_qt_cbf(e, cu, tu, comp, subdiv == 0);
+  }
+  if (subdiv) {
+    for (int i = 0; i < 4; i++) { HmoTU c; tu_child(&c, tu, i, 0); enc_subdiv_cbf_qt(e, cu, &c, bLuma, bChroma); }
+  } else if (bLuma) code_qt_cbf(e, cu, tu, 0, 1);
+}
+/* xEncCoeffQT (+ TEncEntropy::encodeCoeffNxN, TEncEntropy.cpp:660-690) */
+static void enc_coeff_qt(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp, int realCoeff)
+{
+  if (cu->tr_idx[tu->part] > tu->tr_depth) {
+    for (int i = 0; i < 4; i++) { HmoTU c; tu_child(&c, tu, i, 0); enc_coeff_qt(e, cu, &c, comp, realCoeff); }
+    return;
+  }
+  if (comp ? tu->cw == 0 : 0) return;
+  int layer = HMO_LOG2_MAXTU - tu->log2;
+  const int32_t *buf = realCoeff ? cu->coef[comp] : e->qt_coef[comp][layer];
+  int off = comp ? tu->off_c : tu->off_y;
+  if ((cu->cbf[comp][tu->part] >> tu->tr_depth) & 1) {
+    int log2 = comp ? (tu->cw == 4 ? 2 : tu->cw == 8 ? 3 : tu->cw == 16 ? 4 : 5) : tu->log2;
+    hmo_code_coeff_nxn(e, cu, buf + off, log2, comp, comp ? tu_part_c(tu) : tu->part);
+  }
+}
+/* xEncIntraHeader */
+static void enc_intra_header(HmoEnc *e, const HmoCU *cu, int trDepth, int part, int bLuma, int bChroma)
+{
+  if (bLuma) {
+    if (part == 0) code_part_size(e, cu, 0, cu->depth[0]);
+    if (cu->part_size[0] == HMO_SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(e, cu, 0, 0); }
+    else { int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(e, cu, part, 0); }
+  }
+  if (bChroma && part == 0) code_intra_dir_chroma(e, cu, part);
+}
+/* xGetIntraBitsQT */
+static uint32_t intra_bits_qt(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int bLuma, int bChroma)
+{
+  hmo_reset_bits(e);
+  enc_intra_header(e, cu, tu->tr_depth, tu->part, bLuma, bChroma);
+  enc_subdiv_cbf_qt(e, cu, tu, bLuma, bChroma);
+  if (bLuma) enc_coeff_qt(e, cu, tu, 0, 0);
+  if (bChroma) { enc_coeff_qt(e, cu, tu, 1, 0); enc_coeff_qt(e, cu, tu, 2, 0); }
+  return hmo_bits(e);
+}
+/* xGetIntraBitsQTChroma */
+static uint32_t intra_bits_qt_chroma(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp)
+{ hmo_reset_bits(e); enc_coeff_qt(e, cu, tu, comp, 0); return hmo_bits(e); }
+
+/* ------------------------------------------------------------------------------------
+ * one TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387
+ * ---------------------------------------------------------------------------------- */
+static uint8_t *yuv_plane(HmoYuv *b, int comp) { return comp == 0 ? b->y : (comp == 1 ? b->u : b->v); }
+
+static void intra_coding_tu_block(HmoEnc *e, HmoCU *cu, const HmoTU *tu, int comp, uint32_t *dist, int save1load2)
+{
+  if (comp && tu->cw == 0) return;
+  const int d = cu->depth_cu;
+  const int N = comp ? tu->cw : (1 << tu->log2);
+  int log2 = 2; while ((1 << log2) < N) log2++;
+  const int bx = comp ? tu->cx : tu->x, by = comp ? tu->cy : tu->y;
+  const int bs = comp ? 32 : 64;
+  const int part = tu->part;                               /* uiAbsPartIdx = GetAbsPartIdxTU() */
+  const int layer = HMO_LOG2_MAXTU - tu->log2;
+  uint8_t *org = yuv_plane(e->org_yuv[d], comp) + by * bs + bx;
+  uint8_t *pred = yuv_plane(e->pred_temp[d], comp) + by * bs + bx;
+  uint8_t *recqt = yuv_plane(&e->qt_rec[layer], comp) + by * bs + bx;
+  const int sh = comp ? 1 : 0;
+  const int px = (cu->x >> sh) + bx, py = (cu->y >> sh) + by;       /* position in the component plane */
+  uint8_t *recpic = e->rec[comp] + py * e->stride[comp] + px;
+  int32_t *coef = e->qt_coef[comp][layer] + (comp ? tu->off_c : tu->off_y);
+  const int useTS = cu->tskip[comp][part];
+  int mode = cu->intra_dir[comp ? 1 : 0][part];
+  if (comp && mode == HMO_DM_CHROMA) mode = cu->intra_dir[0][part & ~3];
+  e->n_tu_trials++;
+
+  if (save1load2 != 2) {
+    uint8_t ref[4 * 64 + 1], reff[4 * 64 + 1];
+    hmo_build_ref(e, comp, px, py, log2, 0, ref);
+    int filt = hmo_use_filtered_ref(mode, log2, comp == 0);
+    if (filt) hmo_filter_ref(ref, reff, N, comp == 0 && e->p.strong_smoothing);
+    hmo_intra_pred(filt ? reff : ref, 0, log2, mode, comp == 0, pred, bs);
+    if (save1load2 == 1) for (int y = 0; y < N; y++) memcpy(e->shared_pred[comp] + y * N, pred + y * bs, (size_t)N);
+  } else {
+    for (int y = 0; y < N; y++) memcpy(pred + y * bs, e->shared_pred[comp] + y * N, (size_t)N);
+  }
+  int16_t resi[32 * 32];
+  for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) resi[y * N + x] = (int16_t)(org[y * bs + x] - pred[y * bs + x]);
+
+  if (comp == 0) memset(cu->tr_idx + part, tu->tr_depth, (size_t)tu->nparts);     /* setTrIdxSubParts */
+
+  /* transformNxN, TComTrQuant.cpp:1376-1459 */
+  int32_t tcoef[32 * 32];
+  if (useTS) { for (int i = 0; i < N * N; i++) tcoef[i] = (int32_t)resi[i] << (15 - 8 - log2); }
+  else hmo_fwd_transform(resi, N, tcoef, log2, comp == 0 && log2 == 2);
+  int absSum = hmo_rdoq(e, cu, tu, comp, tcoef, coef, log2, comp ? tu_part_c(tu) : part, useTS);
+  { int np = comp ? tu_nparts_c(tu) : tu->nparts;                                   /* setCbfPartRange */
+    memset(cu->cbf[comp] + part, (absSum > 0 ? 1 : 0) << tu->tr_depth, (size_t)np); }
+
+  if (absSum > 0) {
+    int32_t dq[32 * 32];
+    hmo_dequant(coef, dq, N * N, log2, comp ? e->p.qp_c : e->p.qp);
+    if (useTS) { int s = 15 - 8 - log2; for (int i = 0; i < N * N; i++) resi[i] = (int16_t)((dq[i] + (1 << (s - 1))) >> s); }
+    else hmo_inv_transform(dq, resi, N, log2, comp == 0 && log2 == 2);
+  } else {
+    memset(coef, 0, sizeof(int32_t) * (size_t)(N * N));
+    memset(resi, 0, sizeof(int16_t) * (size_t)(N * N));
+  }
+  for (int y = 0; y < N; y++)
+    for (int x = 0; x < N; x++) {
+      int v = pred[y * bs + x] + resi[y * N + x];
+      uint8_t r = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      pred[y * bs + x] = r; recqt[y * bs + x] = r; recpic[y * e->stride[comp] + x] = r;
+    }
+  uint32_t sse = hmo_sse(org, bs, pred, bs, N, N);
+  if (comp) *dist += (uint32_t)(e->p.chroma_weight * (double)sse);                    /* getDistPart, TComRdCost.cpp:447-450 */
+  else *dist += sse;
+}
+
+/* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
+static void store_intra_result_qt(HmoEnc *e, const HmoTU *tu, int comp)
+{
+  if (comp && tu->cw == 0) return;
+  int N = comp ? tu->cw : (1 << tu->log2), layer = HMO_LOG2_MAXTU - tu->log2, bs = comp ? 32 : 64;
+  int bx = comp ? tu->cx : tu->x, by = comp ? tu->cy : tu->y;
+  memcpy(e->ts_coef[comp], e->qt_coef[comp][layer] + (comp ? tu->off_c : tu->off_y), sizeof(int32_t) * (size_t)(N * N));
+  uint8_t *s = yuv_plane(&e->qt_rec[layer], comp) + by * bs + bx, *t = yuv_plane(&e->ts_rec, comp) + by * bs + bx;
+  for (int y = 0; y < N; y++) memcpy(t + y * bs, s + y * bs, (size_t)N);
+}
+static void load_intra_result_qt(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp)
+{
+  if (comp && tu->cw == 0) return;
+  int N = comp ? tu->cw : (1 << tu->log2), layer = HMO_LOG2_MAXTU - tu->log2, bs = comp ? 32 : 64, sh = comp ? 1 : 0;
+  int bx = comp ? tu->cx : tu->x, by = comp ? tu->cy : tu->y;
+  memcpy(e->qt_coef[comp][layer] + (comp ? tu->off_c : tu->off_y), e->ts_coef[comp], sizeof(int32_t) * (size_t)(N * N));
+  uint8_t *t = yuv_plane(&e->qt_rec[layer], comp) + by * bs + bx, *s = yuv_plane(&e->ts_rec, comp) + by * bs + bx;
+  uint8_t *pic = e->rec[comp] + ((cu->y >> sh) + by) * e->stride[comp] + (cu->x >> sh) + bx;
+  for (int y = 0; y < N; y++) { memcpy(t + y * bs, s + y * bs, (size_t)N); memcpy(pic + y * e->stride[comp], s + y * bs, (size_t)N); }
+}
+
+/* ------------------------------------------------------------------------------------
+ * xRecurIntraCodingLumaQT, TEncSearch.cpp:1393-1713
+ * ---------------------------------------------------------------------------------- */
+static void recur_intra_coding_luma_qt(HmoEnc *e, HmoCU *cu, const HmoTU *tu, int checkFirst, uint32_t *distY, double *rdCost)
+{
+  const int d = cu->depth_cu, part = tu->part, trDepth = tu->tr_depth, fullDepth = d + trDepth, log2 = tu->log2;
+  int checkFull = log2 <= HMO_LOG2_MAXTU;
+  int checkSplit = log2 > min_tu_log2_in_cu(cu, part);
+  if (checkFirst && checkFull) checkSplit = 0;                                   /* HHI_RQT_INTRA_SPEEDUP */
+  double singleCost = HMO_MAX_DOUBLE; uint32_t singleDist = 0, singleCbf = 0;
+  int checkTS = e->p.transform_skip && log2 == 2;
+  if (e->p.transform_skip_fast) checkTS = checkTS && (cu->part_size[part] == HMO_SIZE_NxN);
+  int bestModeId = 0;
+
+  if (checkFull) {
+    if (checkTS) {
+      e->slot[fullDepth][CI_QT_TRAFO_ROOT] = e->goon;
+      for (int modeId = 0; modeId < 2; modeId++) {
+        uint32_t tmpDist = 0; double tmpCost;
+        memset(cu->tskip[0] + part, modeId, (size_t)tu->nparts);
+        intra_coding_tu_block(e, cu, tu, 0, &tmpDist, modeId == 0 ? 1 : 2);
+        uint32_t tmpCbf = (cu->cbf[0][part] >> trDepth) & 1;
+        if (modeId == 1 && tmpCbf == 0) tmpCost = HMO_MAX_DOUBLE;
+        else { uint32_t bits = intra_bits_qt(e, cu, tu, 1, 0); tmpCost = calc_rd_cost(e, bits, tmpDist); }
+        if (tmpCost < singleCost) {
+          singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
+          if (bestModeId == 0) { store_intra_result_qt(e, tu, 0); e->slot[fullDepth][CI_TEMP_BEST] = e->goon; }
+        }
+        if (modeId == 0) e->goon = e->slot[fullDepth][CI_QT_TRAFO_ROOT];
+      }
+      memset(cu->tskip[0] + part, bestModeId, (size_t)tu->nparts);
+      if (bestModeId == 0) {
+        load_intra_result_qt(e, cu, tu, 0);
+        memset(cu->cbf[0] + part, (int)(singleCbf << trDepth), (size_t)tu->nparts);
+        e->goon = e->slot[fullDepth][CI_TEMP_BEST];
+      }
+    } else {
+      if (checkSplit) e->slot[fullDepth][CI_QT_TRAFO_ROOT] = e->goon;
+      memset(cu->tskip[0] + part, 0, (size_t)tu->nparts);
+      intra_coding_tu_block(e, cu, tu, 0, &singleDist, 0);
+      if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
+      uint32_t bits = intra_bits_qt(e, cu, tu, 1, 0);
+      singleCost = calc_rd_cost(e, bits, singleDist);
+    }
+  }
+
+  if (checkSplit) {
+    if (checkFull) { e->slot[fullDepth][CI_QT_TRAFO_TEST] = e->goon; e->goon = e->slot[fullDepth][CI_QT_TRAFO_ROOT]; }
+    else e->slot[fullDepth][CI_QT_TRAFO_ROOT] = e->goon;
+    double splitCost = 0.0; uint32_t splitDist = 0, splitCbf = 0;
+    for (int i = 0; i < 4; i++) {
+      HmoTU c; tu_child(&c, tu, i, 0);
+      recur_intra_coding_luma_qt(e, cu, &c, checkFirst, &splitDist, &splitCost);
+      splitCbf |= (cu->cbf[0][c.part] >> c.tr_depth) & 1;
+    }
+    if (splitCbf) for (int o = 0; o < tu->nparts; o++) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
+    e->goon = e->slot[fullDepth][CI_QT_TRAFO_ROOT];
+    uint32_t splitBits = intra_bits_qt(e, cu, tu, 1, 0);
+    splitCost = calc_rd_cost(e, splitBits, splitDist);
+    if (splitCost < singleCost) { *distY += splitDist; *rdCost += splitCost; return; }
+    e->goon = e->slot[fullDepth][CI_QT_TRAFO_TEST];
+    memset(cu->tr_idx + part, trDepth, (size_t)tu->nparts);
+    memset(cu->cbf[0] + part, (int)(singleCbf << trDepth), (size_t)tu->nparts);
+    memset(cu->tskip[0] + part, bestModeId, (size_t)tu->nparts);
+    { int N = 1 << log2, layer = HMO_LOG2_MAXTU - log2;                          /* restore recon for next blocks */
+      uint8_t *s = e->qt_rec[layer].y + tu->y * 64 + tu->x;
+      uint8_t *p = e->rec[0] + (cu->y + tu->y) * e->stride[0] + cu->x + tu->x;
+      for (int y = 0; y < N; y++) memcpy(p + y * e->stride[0], s + y * 64, (size_t)N); }
+  }
+  *distY += singleDist; *rdCost += singleCost;
+}
+
+/* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 */
+static void set_intra_result_luma_qt(HmoEnc *e, HmoCU *cu, const HmoTU *tu, HmoYuv *reco)
+{
+  if (cu->tr_idx[tu->part] == tu->tr_depth) {
+    int N = 1 << tu->log2, layer = HMO_LOG2_MAXTU - tu->log2;
+    memcpy(cu->coef[0] + tu->off_y, e->qt_coef[0][layer] + tu->off_y, sizeof(int32_t) * (size_t)(N * N));
+    for (int y = 0; y < N; y++) memcpy(reco->y + (tu->y + y) * 64 + tu->x, e->qt_rec[layer].y + (tu->y + y) * 64 + tu->x, (size_t)N);
+  } else for (int i = 0; i < 4; i++) { HmoTU c; tu_child(&c, tu, i, 0); set_intra_result_luma_qt(e, cu, &c, reco); }
+}
+
+/* ------------------------------------------------------------------------------------
+ * estIntraPredLumaQT, TEncSearch.cpp:2178-2655
+ * ---------------------------------------------------------------------------------- */
+static void est_intra_pred_luma_qt(HmoEnc *e, HmoCU *cu)
+{
+  const int d = cu->depth_cu;
+  const int initTrDepth = cu->part_size[0] == HMO_SIZE_2Nx2N ? 0 : 1;
+  const int numPU = 1 << (2 * initTrDepth);
+  const int qNumParts = cu->nparts >> 2;
+  uint32_t overallDistY = 0;
+  HmoTU root; tu_root(&root, cu);
+
+  for (int pu = 0; pu < numPU; pu++) {
+    HmoTU tu;
+    if (initTrDepth == 0) tu = root; else tu_child(&tu, &root, pu, 0);
+    const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
+    int numModesForFullRD = hmo_rd_mode_num[log2 - 2];
+    int rdModeList[35]; double candCost[35];
+    /* ---- RMD over the 35 modes (TEncSearch.cpp:2300-2361) ---- */
+    {
+      uint8_t ref[4 * 64 + 1], reff[4 * 64 + 1];
+      hmo_build_ref(e, 0, cu->x + tu.x, cu->y + tu.y, log2, 0, ref);
+      hmo_filter_ref(ref, reff, N, e->p.strong_smoothing);
+      for (int i = 0; i < numModesForFullRD; i++) candCost[i] = HMO_MAX_DOUBLE;
+      uint8_t *org = e->org_yuv[d]->y + tu.y * 64 + tu.x;
+      uint8_t *pred = e->pred_temp[d]->y + tu.y * 64 + tu.x;
+      for (int mode = 0; mode < 35; mode++) {
+        int filt = hmo_use_filtered_ref(mode, log2, 1);
+        hmo_intra_pred(filt ? reff : ref, 0, log2, mode, 1, pred, 64);
+        uint32_t sad = hmo_satd(org, 64, pred, 64, N, N);
+        e->n_rmd++;
+        /* xModeBitsIntra, TEncSearch.cpp:5313-5340: only the intra-dir context and the bit counter are reloaded */
+        e->goon.frac = e->slot[d][CI_CURR_BEST].frac;
+        e->goon.ctx[HMO_CTX_INTRA_LUMA] = e->slot[d][CI_CURR_BEST].ctx[HMO_CTX_INTRA_LUMA];
+        uint8_t orig = cu->intra_dir[0][partOffset];
+        cu->intra_dir[0][partOffset] = (uint8_t)mode;
+        hmo_reset_bits(e);
+        code_intra_dir_luma(e, cu, partOffset, 0);
+        cu->intra_dir[0][partOffset] = orig;
+        uint32_t modeBits = hmo_bits(e);
+        double cost = (double)sad + (double)modeBits * e->p.sqrt_lambda;
+        /* xUpdateCandList, TEncSearch.cpp:5345-5370 */
+        int shift = 0;
+        while (shift < numModesForFullRD && cost < candCost[numModesForFullRD - 1 - shift]) shift++;
+        if (shift != 0) {
+          for (int i = 1; i < shift; i++) {
+            rdModeList[numModesForFullRD - i] = rdModeList[numModesForFullRD - 1 - i];
+            candCost[numModesForFullRD - i] = candCost[numModesForFullRD - 1 - i];
+          }
+          rdModeList[numModesForFullRD - shift] = mode; candCost[numModesForFullRD - shift] = cost;
+        }
+      }
+      int preds[3];
+      int numCand = intra_dir_predictor(e, cu, partOffset, preds);
+      for (int j = 0; j < numCand; j++) {
+        int included = 0;
+        for (int i = 0; i < numModesForFullRD; i++) included |= (preds[j] == rdModeList[i]);
+        if (!included) rdModeList[numModesForFullRD++] = preds[j];
+      }
+    }
+    /* ---- RDO over the candidates, no RQT split (TEncSearch.cpp:2447-2516) ---- */
+    int bestPUMode = 0; uint32_t bestPUDist = 0; double bestPUCost = HMO_MAX_DOUBLE;
+    for (int m = 0; m < numModesForFullRD; m++) {
+      int orgMode = rdModeList[m];
+      memset(cu->intra_dir[0] + partOffset, orgMode, (size_t)tu.nparts);
+      e->goon = e->slot[d][CI_CURR_BEST];
+      uint32_t puDist = 0; double puCost = 0.0;
+      recur_intra_coding_luma_qt(e, cu, &tu, 1, &puDist, &puCost);
+      if (puCost < bestPUCost) {
+        bestPUMode = orgMode; bestPUDist = puDist; bestPUCost = puCost;
+        set_intra_result_luma_qt(e, cu, &tu, e->reco_temp[d]);
+        memcpy(e->tmp_tr_idx, cu->tr_idx + partOffset, (size_t)tu.nparts);
+        for (int c = 0; c < 3; c++) { memcpy(e->tmp_cbf[c], cu->cbf[c] + partOffset, (size_t)tu.nparts); memcpy(e->tmp_tskip[c], cu->tskip[c] + partOffset, (size_t)tu.nparts); }
+      }
+    }
+    /* ---- best mode again with the full RQT (TEncSearch.cpp:2518-2586) ---- */
+    {
+      int orgMode = bestPUMode;
+      memset(cu->intra_dir[0] + partOffset, orgMode, (size_t)tu.nparts);
+      e->goon = e->slot[d][CI_CURR_BEST];
+      uint32_t puDist = 0; double puCost = 0.0;
+      recur_intra_coding_luma_qt(e, cu, &tu, 0, &puDist, &puCost);
+      if (puCost < bestPUCost) {
+        bestPUMode = orgMode; bestPUDist = puDist; bestPUCost = puCost;
+        set_intra_result_luma_qt(e, cu, &tu, e->reco_temp[d]);
+        memcpy(e->tmp_tr_idx, cu->tr_idx + partOffset, (size_t)tu.nparts);
+        for (int c = 0; c < 3; c++) { memcpy(e->tmp_cbf[c], cu->cbf[c] + partOffset, (size_t)tu.nparts); memcpy(e->tmp_tskip[c], cu->tskip[c] + partOffset, (size_t)tu.nparts); }
+      }
+    }
+    overallDistY += bestPUDist;
+    memcpy(cu->tr_idx + partOffset, e->tmp_tr_idx, (size_t)tu.nparts);
+    for (int c = 0; c < 3; c++) { memcpy(cu->cbf[c] + partOffset, e->tmp_cbf[c], (size_t)tu.nparts); memcpy(cu->tskip[c] + partOffset, e->tmp_tskip[c], (size_t)tu.nparts); }
+    if (pu != numPU - 1) {                               /* recon of the best PU for the next PU's prediction */
+      uint8_t *s = e->reco_temp[d]->y + tu.y * 64 + tu.x;
+      uint8_t *p = e->rec[0] + (cu->y + tu.y) * e->stride[0] + cu->x + tu.x;
+      for (int y = 0; y < N; y++) memcpy(p + y * e->stride[0], s + y * 64, (size_t)N);
+    }
+    memset(cu->intra_dir[0] + partOffset, bestPUMode, (size_t)tu.nparts);
+  }
+  if (numPU > 1) {
+    uint8_t cy = 0, cu_ = 0, cv = 0;
+    for (int p = 0, idx = 0; p < 4; p++, idx += qNumParts) {
+      cy |= (cu->cbf[0][idx] >> 1) & 1; cu_ |= (cu->cbf[1][idx] >> 1) & 1; cv |= (cu->cbf[2][idx] >> 1) & 1;
+    }
+    for (int o = 0; o < 4 * qNumParts; o++) { cu->cbf[0][o] |= cy; cu->cbf[1][o] |= cu_; cu->cbf[2][o] |= cv; }
+  }
+  e->goon = e->slot[d][CI_CURR_BEST];
+  cu->dist = overallDistY;
+}
+
+/* ------------------------------------------------------------------------------------
+ * chroma: xRecurIntraChromaCodingQT, TEncSearch.cpp:1916-2120
+ * ---------------------------------------------------------------------------------- */
+static void recur_intra_chroma_coding_qt(HmoEnc *e, HmoCU *cu, const HmoTU *tu, uint32_t *dist)
+{
+  const int part = tu->part, trDepth = tu->tr_depth;
+  if (cu->tr_idx[part] == trDepth) {
+    if (tu->cw == 0) return;
+    const int fullDepth = cu->depth_cu + trDepth;
+    int checkTS = e->p.transform_skip && tu->cw <= 4;
+    if (e->p.transform_skip_fast) {
+      checkTS = checkTS && (tu->log2 == 2);
+      if (checkTS) {
+        int nb = 0, maxp = part + (tu->c_code_all ? 1 : 4);
+        for (int p = part; p < maxp; p++) nb += cu->tskip[0][p];
+        checkTS = checkTS && (nb > 0);
+      }
+    }
+    const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
+    for (int comp = 1; comp < 3; comp++) {
+      e->slot[fullDepth][CI_QT_TRAFO_ROOT] = e->goon;
+      double singleCost = HMO_MAX_DOUBLE; int bestModeId = 0; uint32_t singleDistC = 0, singleCbfC = 0;
+      double tmpCost = 0; int bestTS = 0;
+      const int modesToTest = checkTS ? 2 : 1;
+      int currModeId = 0;
+      for (int tsMode = 0; tsMode < modesToTest; tsMode++) {
+        memset(cu->tskip[comp] + subPart, tsMode, (size_t)nPartsC);
+        currModeId++;
+        const int isOne = modesToTest == 1, isLast = currModeId == modesToTest;
+        int s1l2 = isOne ? 0 : (tsMode == 0 ? 1 : 2);
+        uint32_t tmpDist = 0;
+        intra_coding_tu_block(e, cu, tu, comp, &tmpDist, s1l2);
+        uint32_t tmpCbf = (cu->cbf[comp][subPart] >> trDepth) & 1;
+        if (tsMode == 1 && tmpCbf == 0) tmpCost = HMO_MAX_DOUBLE;
+        else if (!isOne) { uint32_t bits = intra_bits_qt_chroma(e, cu, tu, comp); tmpCost = calc_rd_cost(e, bits, tmpDist); }
+        if (tmpCost < singleCost) {
+          singleCost = tmpCost; singleDistC = tmpDist; bestTS = tsMode; bestModeId = currModeId; singleCbfC = tmpCbf;
+          if (!isOne && !isLast) { store_intra_result_qt(e, tu, comp); e->slot[fullDepth][CI_TEMP_BEST] = e->goon; }
+        }
+        if (!isOne && !isLast) e->goon = e->slot[fullDepth][CI_QT_TRAFO_ROOT];
+      }
+      if (bestModeId < modesToTest) {
+        load_intra_result_qt(e, cu, tu, comp);
+        memset(cu->cbf[comp] + subPart, (int)(singleCbfC << trDepth), (size_t)nPartsC);
+        e->goon = e->slot[fullDepth][CI_TEMP_BEST];
+      }
+      memset(cu->tskip[comp] + subPart, bestTS, (size_t)nPartsC);
+      *dist += singleDistC;
+    }
+  } else {
+    uint32_t splitCbf[3] = { 0, 0, 0 };
+    for (int i = 0; i < 4; i++) {
+      HmoTU c; tu_child(&c, tu, i, 0);
+      recur_intra_chroma_coding_qt(e, cu, &c, dist);
+      for (int comp = 1; comp < 3; comp++) splitCbf[comp] |= (cu->cbf[comp][c.part] >> c.tr_depth) & 1;
+    }
+    for (int comp = 1; comp < 3; comp++)
+      if (splitCbf[comp]) for (int o = 0; o < tu->nparts; o++) cu->cbf[comp][part + o] |= (uint8_t)(1 << trDepth);
+  }
+}
+/* xSetIntraResultChromaQT, TEncSearch.cpp:2126-2175 */
+static void set_intra_result_chroma_qt(HmoEnc *e, HmoCU *cu, const HmoTU *tu, HmoYuv *reco)
+{
+  if (tu->cw == 0) return;
+  if (cu->tr_idx[tu->part] == tu->tr_depth) {
+    int N = tu->cw, layer = HMO_LOG2_MAXTU - tu->log2;
+    for (int comp = 1; comp < 3; comp++) {
+      memcpy(cu->coef[comp] + tu->off_c, e->qt_coef[comp][layer] + tu->off_c, sizeof(int32_t) * (size_t)(N * N));
+      uint8_t *s = yuv_plane(&e->qt_rec[layer], comp), *t = yuv_plane(reco, comp);
+      for (int y = 0; y < N; y++) memcpy(t + (tu->cy + y) * 32 + tu->cx, s + (tu->cy + y) * 32 + tu->cx, (size_t)N);
+    }
+  } else for (int i = 0; i < 4; i++) { HmoTU c; tu_child(&c, tu, i, 0); set_intra_result_chroma_qt(e, cu, &c, reco); }
+}
+/* estIntraPredChromaQT, TEncSearch.cpp:2661-2810 (4:2:0: one chroma PU per CU) */
+static void est_intra_pred_chroma_qt(HmoEnc *e, HmoCU *cu)
+{
+  const int d = cu->depth_cu, n = cu->nparts;
+  HmoTU tu; tu_root(&tu, cu);
+  int bestMode = 0; uint32_t bestDist = 0; double bestCost = HMO_MAX_DOUBLE;
+  int modeList[5];
+  allowed_chroma_dir(cu, 0, modeList);
+  for (int m = 0; m < 5; m++) {
+    e->goon = e->slot[d][CI_CURR_BEST];
+    uint32_t dist = 0;
+    memset(cu->intra_dir[1], modeList[m], (size_t)n);
+    recur_intra_chroma_coding_qt(e, cu, &tu, &dist);
+    if (e->p.transform_skip) e->goon = e->slot[d][CI_CURR_BEST];
+    uint32_t bits = intra_bits_qt(e, cu, &tu, 0, 1);
+    double cost = calc_rd_cost(e, bits, dist);
+    if (cost < bestCost) {
+      bestCost = cost; bestDist = dist; bestMode = modeList[m];
+      set_intra_result_chroma_qt(e, cu, &tu, e->reco_temp[d]);
+      for (int c = 1; c < 3; c++) { memcpy(e->tmp_cbf[c], cu->cbf[c], (size_t)n); memcpy(e->tmp_tskip[c], cu->tskip[c], (size_t)n); }
+    }
+  }
+  for (int c = 1; c < 3; c++) { memcpy(cu->cbf[c], e->tmp_cbf[c], (size_t)n); memcpy(cu->tskip[c], e->tmp_tskip[c], (size_t)n); }
+  memset(cu->intra_dir[1], bestMode, (size_t)n);
+  cu->dist += bestDist;
+  e->goon = e->slot[d][CI_CURR_BEST];
+}
+
+/* ------------------------------------------------------------------------------------
+ * final-order CU syntax (TEncEntropy::encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400)
+ * ---------------------------------------------------------------------------------- */
+static void encode_transform(HmoEnc *e, const HmoCU *cu, int cuPart, const HmoTU *tu)
+{
+  /* all indices below are relative to `cu`; cuPart = first partition of the coded CU inside `cu` */
+  const int part = cuPart + tu->part;
+  const int trIdx = tu->tr_depth;
+  const int subdiv = cu->tr_idx[part] > trIdx;
+  int cbf[3];
+  for (int c = 0; c < 3; c++) cbf[c] = (cu->cbf[c][part] >> trIdx) & 1;
+  const int cuDepth = cu->depth[part];
+  if (cu->part_size[part] == HMO_SIZE_NxN && trIdx == 0) { }
+  else if (tu->log2 > HMO_LOG2_MAXTU) { }
+  else if (tu->log2 == HMO_LOG2_MINTU) { }
+  else if (tu->log2 == min_tu_log2_in_cu(cu, part)) { }
+  else hmo_enc_bin(e, subdiv, HMO_CTX_SUBDIV + 5 - tu->log2);
+  (void)cuDepth;
+  const int first = trIdx == 0;
+  for (int comp = 1; comp < 3; comp++) {
+    if (first || tu->c_code_all) {
+      if (first || ((cu->cbf[comp][part] >> (trIdx - 1)) & 1)) {
+        int canQuadSplit = tu->cwo >= 8;
+        int lowestDepth = trIdx + ((subdiv && !canQuadSplit) ? 1 : 0);
+        int pc = cuPart + tu_part_c(tu);
+        hmo_enc_bin(e, (cu->cbf[comp][pc] >> lowestDepth) & 1, HMO_CTX_CBF_CHROMA + trIdx);
+      }
+    }
+  }
+  if (subdiv) {
+    for (int i = 0; i < 4; i++) { HmoTU c; tu_child(&c, tu, i, 1); encode_transform(e, cu, cuPart, &c); }
+    return;
+  }
+  hmo_enc_bin(e, cbf[0], HMO_CTX_CBF_LUMA + (trIdx == 0 ? 1 : 0));
+  /* coefficients: Y, Cb, Cr of this TU.  A view CU positioned at cuPart gives codeCoeffNxN the
+   * right relative indices. */
+  for (int comp = 0; comp < 3; comp++) {
+    if (comp && tu->cw == 0) continue;
+    if (!cbf[comp]) continue;
+    int N = comp ? tu->cw : (1 << tu->log2), log2 = 2; while ((1 << log2) < N) log2++;
+    const int32_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu->off_c) : (cuPart * 16 + tu->off_y));
+    /* hmo_code_coeff_nxn reads intra_dir/tskip at `part`; give absolute index inside cu */
+    hmo_code_coeff_nxn(e, cu, coef, log2, comp, cuPart + (comp ? tu_part_c(tu) : tu->part));
+  }
+}
+/* CU syntax as coded by xCheckRDCostIntra (TEncCu.cpp:2117-2141) and xEncodeCU (:1753-1778) */
+static void encode_cu_syntax(HmoEnc *e, const HmoCU *cu, int cuPart, int depth)
+{
+  code_part_size(e, cu, cuPart, depth);
+  code_intra_dir_luma(e, cu, cuPart, 1);                       /* encodePredInfo */
+  code_intra_dir_chroma(e, cu, cuPart);
+  HmoTU root;
+  memset(&root, 0, sizeof(root));
+  root.log2 = 6 - depth; root.nparts = HMO_NPART >> (2 * depth);
+  root.cw = root.cwo = (HMO_CTU >> depth) >> 1; root.c_code_all = 1;
+  encode_transform(e, cu, cuPart, &root);
+}
+
+/* ------------------------------------------------------------------------------------
+ * xCheckRDCostIntra, TEncCu.cpp:2064-2157 ; xCheckBestMode :2213-2255
+ * ---------------------------------------------------------------------------------- */
+static int check_best_mode(HmoEnc *e, int d)
+{
+  if (e->temp[d]->cost < e->best[d]->cost) {
+    HmoCU *t = e->best[d]; e->best[d] = e->temp[d]; e->temp[d] = t;
+    HmoYuv *y = e->reco_best[d]; e->reco_best[d] = e->reco_temp[d]; e->reco_temp[d] = y;
+    e->slot[d][CI_NEXT_BEST] = e->slot[d][CI_TEMP_BEST];
+    return 1;
+  }
+  return 0;
+}
+static void check_rd_cost_intra(HmoEnc *e, int d, int partSize)
+{
+  HmoCU *cu = e->temp[d];
+  const int n = cu->nparts, s = cu_size(cu);
+  memset(cu->part_size, partSize, (size_t)n);
+  memset(cu->pred_mode, HMO_MODE_INTRA, (size_t)n);
+  est_intra_pred_luma_qt(e, cu);
+  for (int y = 0; y < s; y++) memcpy(e->rec[0] + (cu->y + y) * e->stride[0] + cu->x, e->reco_temp[d]->y + y * 64, (size_t)s);
+  est_intra_pred_chroma_qt(e, cu);
+  hmo_reset_bits(e);
+  encode_cu_syntax(e, cu, 0, d);
+  e->slot[d][CI_TEMP_BEST] = e->goon;
+  cu->bits = hmo_bits(e);
+  cu->bins = e->goon_bins;
+  cu->cost = calc_rd_cost(e, cu->bits, cu->dist);
+  check_best_mode(e, d);
+}
+
+static void copy_reco_to_pic(HmoEnc *e, const HmoYuv *r, int x, int y, int s)
+{
+  for (int c = 0; c < 3; c++) {
+    int sh = c ? 1 : 0, bs = c ? 32 : 64, w = (c ? e->p.width / 2 : e->p.width), h = (c ? e->p.height / 2 : e->p.height);
+    const uint8_t *src = c == 0 ? r->y : (c == 1 ? r->u : r->v);
+    int px = x >> sh, py = y >> sh, n = s >> sh;
+    for (int yy = 0; yy < n && py + yy < h; yy++) {
+      int cw = n; if (px + cw > w) cw = w - px;
+      if (cw > 0) memcpy(e->rec[c] + (py + yy) * e->stride[c] + px, src + yy * bs, (size_t)cw);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------
+ * xCompressCU, TEncCu.cpp:460-1616 (fork state = Training: no early decisions)
+ * ---------------------------------------------------------------------------------- */
+static void compress_cu(HmoEnc *e, int d)
+{
+  HmoCU *bestInit = e->best[d];
+  const int x = bestInit->x, y = bestInit->y, zidx = bestInit->zidx, s = HMO_CTU >> d;
+  const int boundary = !((x + s - 1 < e->p.width) && (y + s - 1 < e->p.height));
+  if (!boundary) {
+    for (int yy = 0; yy < s; yy++) memcpy(e->org_yuv[d]->y + yy * 64, e->org[0] + (y + yy) * e->stride[0] + x, (size_t)s);
+    for (int yy = 0; yy < s / 2; yy++) {
+      memcpy(e->org_yuv[d]->u + yy * 32, e->org[1] + (y / 2 + yy) * e->stride[1] + x / 2, (size_t)(s / 2));
+      memcpy(e->org_yuv[d]->v + yy * 32, e->org[2] + (y / 2 + yy) * e->stride[2] + x / 2, (size_t)(s / 2));
+    }
+    cu_init(e->temp[d], d, x, y, zidx);
+    check_rd_cost_intra(e, d, HMO_SIZE_2Nx2N);
+    cu_init(e->temp[d], d, x, y, zidx);
+    if (d == HMO_MAXDEPTH) {
+      check_rd_cost_intra(e, d, HMO_SIZE_NxN);
+      cu_init(e->temp[d], d, x, y, zidx);
+    }
+    if (e->best[d]->cost != HMO_MAX_DOUBLE) {               /* fork: TEncCu.cpp:1224 */
+      hmo_reset_bits(e);
+      code_split_flag(e, e->best[d], 0, d);
+      e->best[d]->bits += hmo_bits(e);
+      e->best[d]->bins += e->goon_bins;
+      e->best[d]->cost = calc_rd_cost(e, e->best[d]->bits, e->best[d]->dist);
+    }
+  }
+  cu_init(e->temp[d], d, x, y, zidx);
+  if (d < HMO_MAXDEPTH) {
+    const int nd = d + 1, hs = s >> 1, qn = (HMO_NPART >> (2 * nd));
+    for (int i = 0; i < 4; i++) {
+      int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
+      cu_init(e->best[nd], nd, sx, sy, zidx + i * qn);
+      cu_init(e->temp[nd], nd, sx, sy, zidx + i * qn);
+      if (sx < e->p.width && sy < e->p.height) {
+        if (i == 0) e->slot[nd][CI_CURR_BEST] = e->slot[d][CI_CURR_BEST];
+        else e->slot[nd][CI_CURR_BEST] = e->slot[nd][CI_NEXT_BEST];
+        compress_cu(e, nd);
+        cu_copy_part_from(e->temp[d], e->best[nd], i);
+        /* xCopyYuv2Tmp */
+        for (int yy = 0; yy < hs; yy++) memcpy(e->reco_temp[d]->y + ((i >> 1) * hs + yy) * 64 + (i & 1) * hs, e->reco_best[nd]->y + yy * 64, (size_t)hs);
+        for (int yy = 0; yy < hs / 2; yy++) {
+          memcpy(e->reco_temp[d]->u + ((i >> 1) * hs / 2 + yy) * 32 + (i & 1) * hs / 2, e->reco_best[nd]->u + yy * 32, (size_t)(hs / 2));
+          memcpy(e->reco_temp[d]->v + ((i >> 1) * hs / 2 + yy) * 32 + (i & 1) * hs / 2, e->reco_best[nd]->v + yy * 32, (size_t)(hs / 2));
+        }
+      } else {
+        cu_copy_to_pic(e, e->best[nd]);
+        cu_copy_part_from(e->temp[d], e->best[nd], i);
+      }
+    }
+    if (!boundary) {
+      hmo_reset_bits(e);
+      code_split_flag(e, e->temp[d], 0, d);
+      e->temp[d]->bits += hmo_bits(e);
+      e->temp[d]->bins += e->goon_bins;
+    }
+    e->temp[d]->cost = calc_rd_cost(e, e->temp[d]->bits, e->temp[d]->dist);
+    e->slot[d][CI_TEMP_BEST] = e->slot[nd][CI_NEXT_BEST];
+    check_best_mode(e, d);
+  }
+  cu_copy_to_pic(e, e->best[d]);
+  copy_reco_to_pic(e, e->reco_best[d], x, y, s);
+}
+
+/* ------------------------------------------------------------------------------------
+ * encodeCtu replay: TEncCu::xEncodeCU, TEncCu.cpp:1679-1778
+ * ---------------------------------------------------------------------------------- */
+static void encode_cu(HmoEnc *e, const HmoCU *ctu, int part, int depth, int lastCtuOfSlice)
+{
+  const int cx = ctu->x + part_x(part), cy = ctu->y + part_y(part), s = HMO_CTU >> depth;
+  int boundary = 0;
+  if (cx + s - 1 < e->p.width && cy + s - 1 < e->p.height) code_split_flag(e, ctu, part, depth);
+  else boundary = 1;
+  if ((depth < ctu->depth[part] && depth < HMO_MAXDEPTH) || boundary) {
+    int qn = (HMO_NPART >> (2 * depth)) >> 2;
+    for (int i = 0; i < 4; i++) {
+      int p = part + i * qn;
+      if (ctu->x + part_x(p) < e->p.width && ctu->y + part_y(p) < e->p.height) encode_cu(e, ctu, p, depth + 1, lastCtuOfSlice);
+    }
+    return;
+  }
+  encode_cu_syntax(e, ctu, part, depth);
+  /* finishCU, TEncCu.cpp:1629-1645 ; isLastSubCUOfCtu TComDataCU.cpp */
+  {
+    int w = e->p.width, h = e->p.height;
+    int granW = 8, granH = 8;                                   /* min CU */
+    int rx = cx + s, ry = cy + s;
+    int lastX = ((rx % HMO_CTU) == 0) || rx == w || rx > w;
+    int lastY = ((ry % HMO_CTU) == 0) || ry == h || ry > h;
+    (void)granW; (void)granH;
+    if (lastX && lastY && !lastCtuOfSlice) hmo_enc_bin_trm(e, 0);
+  }
+}
+
+/* ------------------------------------------------------------------------------------
+ * public API
+ * ---------------------------------------------------------------------------------- */
+void hmo_params_default(HmoParams *p, int width, int height, int qp)
+{
+  memset(p, 0, sizeof(*p));
+  p->width = width; p->height = height; p->qp = qp; p->slice_ctus = 0;
+  p->transform_skip = 1; p->transform_skip_fast = 1; p->sign_hiding = 1; p->strong_smoothing = 1;
+  hmo_params_finish(p);
+}
+/* TEncSlice::initEncSlice lambda (TEncSlice.cpp:686-706) + setUpLambda (:496-524) + TComRdCost::setLambda */
+void hmo_params_finish(HmoParams *p)
+{
+  double qp_temp = (double)p->qp - 12;
+  double lambda = 0.57 * pow(2.0, qp_temp / 3.0);
+  p->lambda = lambda;
+  p->sqrt_lambda = sqrt(lambda);
+  int qpc = p->qp < 0 ? p->qp : hmo_chroma_scale[p->qp > 57 ? 57 : p->qp];
+  p->qp_c = qpc;
+  double w = pow(2.0, (p->qp - qpc) / 3.0);
+  p->chroma_weight = w;
+  p->rdoq_lambda[0] = lambda; p->rdoq_lambda[1] = lambda / w; p->rdoq_lambda[2] = lambda / w;
+}
+
+HmoEnc *hmo_create(const HmoParams *p)
+{
+  hmo_init_tables();
+  HmoEnc *e = (HmoEnc *)calloc(1, sizeof(HmoEnc));
+  e->p = *p;
+  e->w_ctu = (p->width + 63) / 64; e->h_ctu = (p->height + 63) / 64; e->n_ctu = e->w_ctu * e->h_ctu;
+  e->pic = (HmoCtu *)calloc((size_t)e->n_ctu, sizeof(HmoCtu));
+  e->replay_bits = (uint32_t *)calloc((size_t)e->n_ctu, sizeof(uint32_t));
+  for (int d = 0; d < 4; d++) {
+    e->best[d] = (HmoCU *)calloc(1, sizeof(HmoCU)); e->temp[d] = (HmoCU *)calloc(1, sizeof(HmoCU));
+    e->org_yuv[d] = (HmoYuv *)calloc(1, sizeof(HmoYuv)); e->pred_temp[d] = (HmoYuv *)calloc(1, sizeof(HmoYuv));
+    e->reco_best[d] = (HmoYuv *)calloc(1, sizeof(HmoYuv)); e->reco_temp[d] = (HmoYuv *)calloc(1, sizeof(HmoYuv));
+  }
+  return e;
+}
+void hmo_destroy(HmoEnc *e)
+{
+  if (!e) return;
+  for (int d = 0; d < 4; d++) { free(e->best[d]); free(e->temp[d]); free(e->org_yuv[d]); free(e->pred_temp[d]); free(e->reco_best[d]); free(e->reco_temp[d]); }
+  free(e->pic); free(e->replay_bits); free(e);
+}
+void hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const uint8_t *orgV, uint8_t *recY, uint8_t *recU, uint8_t *recV)
+{
+  e->org[0] = orgY; e->org[1] = orgU; e->org[2] = orgV;
+  e->rec[0] = recY; e->rec[1] = recU; e->rec[2] = recV;
+  e->stride[0] = e->p.width; e->stride[1] = e->stride[2] = e->p.width / 2;
+}
+int hmo_num_ctus(const HmoEnc *e) { return e->n_ctu; }
+const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
+const HmoCabac *hmo_get_cabac(const HmoEnc *e) { return &e->slot[0][CI_CURR_BEST]; }
+uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int a) { return e->replay_bits[a]; }
+
+/* TComDataCU::initCtu defaults (TComDataCU.cpp:474-560) */
+static void pic_ctu_init(const HmoEnc *e, HmoCtu *c)
+{
+  memset(c, 0, sizeof(*c));
+  memset(c->part_size, HMO_SIZE_NONE, HMO_NPART);
+  memset(c->pred_mode, HMO_MODE_NONE, HMO_NPART);
+  memset(c->width, HMO_CTU, HMO_NPART); memset(c->height, HMO_CTU, HMO_NPART);
+  memset(c->qp, e->p.qp, HMO_NPART);
+  memset(c->intra_dir[0], HMO_DC, HMO_NPART);
+  c->total_cost = HMO_MAX_DOUBLE;
+}
+
+/* one iteration of the CTU loop of TEncSlice::compressSlice, TEncSlice.cpp:1380-1551 */
+void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
+{
+  const int sliceLen = e->p.slice_ctus > 0 ? e->p.slice_ctus : e->n_ctu;
+  const int sliceStart = (ctuRsAddr / sliceLen) * sliceLen;
+  int sliceEnd = sliceStart + sliceLen; if (sliceEnd > e->n_ctu) sliceEnd = e->n_ctu;
+  e->cur_ctu = ctuRsAddr; e->slice_start = sliceStart;
+  if (ctuRsAddr == sliceStart) hmo_cabac_init(&e->slot[0][CI_CURR_BEST], e->p.qp);     /* resetEntropy */
+  pic_ctu_init(e, &e->pic[ctuRsAddr]);
+  e->goon = e->slot[0][CI_CURR_BEST];
+  e->goon_bins = 0;
+  /* compressCtu, TEncCu.cpp:329-356 */
+  int x = (ctuRsAddr % e->w_ctu) * HMO_CTU, y = (ctuRsAddr / e->w_ctu) * HMO_CTU;
+  cu_init(e->best[0], 0, x, y, 0);
+  cu_init(e->temp[0], 0, x, y, 0);
+  compress_cu(e, 0);
+  /* encodeCtu on [0][CI_CURR_BEST] (TEncSlice.cpp:1474-1487): replay the winner */
+  {
+    HmoCU *view = e->temp[0];
+    const HmoCtu *p = &e->pic[ctuRsAddr];
+    view->depth_cu = 0; view->x = x; view->y = y; view->zidx = 0; view->nparts = HMO_NPART;
+    memcpy(view->depth, p->depth, HMO_NPART); memcpy(view->part_size, p->part_size, HMO_NPART);
+    memcpy(view->pred_mode, p->pred_mode, HMO_NPART); memcpy(view->tr_idx, p->tr_idx, HMO_NPART);
+    for (int c = 0; c < 3; c++) { memcpy(view->tskip[c], p->tskip[c], HMO_NPART); memcpy(view->cbf[c], p->cbf[c], HMO_NPART); }
+    memcpy(view->intra_dir[0], p->intra_dir[0], HMO_NPART); memcpy(view->intra_dir[1], p->intra_dir[1], HMO_NPART);
+    memcpy(view->coef[0], p->coeff_y, sizeof(p->coeff_y)); memcpy(view->coef[1], p->coeff_cb, sizeof(p->coeff_cb)); memcpy(view->coef[2], p->coeff_cr, sizeof(p->coeff_cr));
+    e->goon = e->slot[0][CI_CURR_BEST];
+    hmo_reset_bits(e);
+    encode_cu(e, view, 0, 0, ctuRsAddr == sliceEnd - 1);
+    e->replay_bits[ctuRsAddr] = hmo_bits(e);
+    e->slot[0][CI_CURR_BEST] = e->goon;
+  }
+}
+void hmo_compress_frame(HmoEnc *e)
+{
+  for (int a = 0; a < e->n_ctu; a++) hmo_compress_ctu(e, a);
+}
