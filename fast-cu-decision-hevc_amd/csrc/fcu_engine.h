@@ -1,0 +1,1736 @@
+/*
+ * fcu_engine.h -- the CTU decision engine: one 64-lane wavefront per chain.
+ *
+ * A chain is the unit that HM processes strictly sequentially (a slice of an I picture:
+ * reconstructed neighbours, CABAC contexts and neighbour decisions all flow CTU to CTU,
+ * SURVEY.md 7.1).  Chains are independent, so the GPU runs thousands of them side by
+ * side, one wavefront each; inside a chain the wave
+ *   - spreads pixel work (35-mode prediction, Hadamard SATD, DCT/DST, dequant, recon, SSE)
+ *     across its 64 lanes,
+ *   - evaluates the independent RDO candidates of a PU (each restarts from the same CABAC
+ *     snapshot, TEncSearch.cpp:2457) on different lanes: RDOQ and bit counting are
+ *     lane-private serial code,
+ *   - keeps CABAC snapshots, reference samples and the SATD staging buffer in LDS.
+ *
+ * Code style: "phases".  FCU_FOR_LANES { ... } is per-lane code followed by a workgroup
+ * barrier; everything outside such a block is wave-uniform, reads memory only, and never
+ * stores.  All cross-lane communication goes through memory (LDS / the chain's global
+ * scratch).  The same source therefore also builds as a plain C++ wave emulator
+ * (-DFCU_EMU, tests only) used to check the engine's logic where no GPU is present.
+ *
+ * Every routine cites the reference code it replaces (paths relative to the reference tree).
+ */
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "../../include/fcu.h"
+
+#ifdef FCU_EMU
+#include <math.h>
+#include <stdlib.h>
+#define FCU_DEV static inline
+#define FCU_TABLE static const
+#define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
+#define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
+#define FCU_FLOOR(x) floor(x)
+#else
+#define FCU_DEV __device__ static
+#define FCU_TABLE __device__ static const
+#define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
+#define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define FCU_FLOOR(x) floor(x)
+#endif
+#define FCU_SERIAL FCU_FOR_LANES if (lane == 0)
+
+#include "fcu_tables.h"
+
+namespace fcu {
+
+/* ---- constants ------------------------------------------------------------------------ */
+enum { CTU = 64, MAXDEPTH = 3, NPART = 256, LOG2_MAXTU = 5, LOG2_MINTU = 2, TU_MAXDEPTH_INTRA = 3 };
+enum { SIZE_2Nx2N = 0, SIZE_NxN = 3, SIZE_NONE = 8, MODE_INTRA = 1, MODE_NONE = 2 };
+enum { PLANAR = 0, DC = 1, HOR = 10, VER = 26, DM_CHROMA = 36 };
+/* context layout (counts: TLibCommon/ContextTables.h:49-161) */
+enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5, CTX_CBF_LUMA = 6, CTX_CBF_CHROMA = 11,
+       CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
+       CTX_TSKIP = 157, NCTX = 160 };
+enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
+enum { MAXVC = 20, POOL = 5120, DIFFN = 2048 };
+#define FCU_MAX_DOUBLE 1.7e+308
+
+/* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
+struct Cabac { uint8_t ctx[NCTX]; uint64_t frac; uint32_t bins; uint32_t pad_; };
+
+struct Params {
+  int width, height, qp, qp_c, slice_ctus;
+  int transform_skip, ts_fast, sign_hiding, strong_smoothing;
+  double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
+  double err_scale[2][4];     /* [luma/chroma][log2-2]   setErrScaleCoeff, TComTrQuant.cpp:3018-3040 */
+  long long rd_factor[2];     /* sign-hiding rdFactor,   TComTrQuant.cpp:2444-2447 */
+};
+
+/* per-chain descriptor in HBM */
+struct Chain {
+  const uint8_t *org[3];
+  uint8_t *rec[3];
+  int stride[3];
+  fcu_ctu_out *out;
+  Params p;
+  int w_ctu, h_ctu, n_ctu;
+  int next_ctu;
+  Cabac state;                 /* m_pppcRDSbacCoder[0][CI_CURR_BEST] between CTUs */
+  unsigned long long n_tu_trials;
+};
+
+/* per-depth working CU (TComDataCU best/temp objects, TEncCu.cpp:163-198) */
+struct CuObj {
+  double cost; uint32_t dist, bits, bins;
+  int depth_cu, x, y, zidx, nparts;
+  uint8_t depth[NPART]; int8_t part_size[NPART], pred_mode[NPART]; uint8_t tr_idx[NPART];
+  uint8_t tskip[3][NPART], cbf[3][NPART], intra_dir[2][NPART];
+  int16_t coef[3][CTU * CTU];
+};
+struct Yuv { uint8_t y[64 * 64], u[32 * 32], v[32 * 32]; };
+
+/* per-chain scratch in HBM (L2 resident working set) */
+struct Scratch {
+  CuObj cu[4][2];
+  Yuv org[4], predt[4], reco[4][2];
+  Yuv qt_rec[4];                                   /* m_pcQTTempTComYuv[layer] */
+  int16_t qt_coef[3][4][CTU * CTU];                /* m_ppcQTTempCoeff[comp][layer] */
+  int16_t ts_coef[3][1024]; Yuv ts_rec; uint8_t shared_pred[3][1024];
+  uint8_t tmp_tr_idx[NPART], tmp_cbf[NPART], tmp_tskip[NPART];
+  uint8_t tmpc_cbf[2][NPART], tmpc_tskip[2][NPART];
+  /* candidate pools: slot v occupies [v*N*N, (v+1)*N*N) */
+  uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; int16_t p_qcoef[POOL]; uint8_t p_rec[POOL];
+  /* RDOQ locals (TComTrQuant.cpp:2082-2095) */
+  double r_cc[POOL], r_cs[POOL], r_c0[POOL]; int32_t r_up[POOL], r_dn[POOL], r_sd[POOL], r_du[POOL];
+};
+
+/* per-chain LDS */
+struct Shared {
+  Cabac goon;
+  Cabac slot[MAXDEPTH + 2][CI_NUM];
+  Cabac lane[MAXVC];
+  uint8_t ref[264], reff[264];
+  int16_t diff[DIFFN];
+  int32_t colsum[512];
+  uint32_t sad[36];
+  int dc;
+  int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
+  /* PU / TU mailbox written by serial blocks */
+  int rd_mode[12]; int n_rd;
+  int preds[3]; int n_mpm;
+  int vc_abs[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];
+  int pu_best_vc, pu_best_mode; uint32_t pu_best_dist; double pu_best_cost;
+  /* sequential TU trial mailbox */
+  int t_abs; uint32_t t_dist;
+  /* RQT recursion results */
+  double q_cost[4]; uint32_t q_dist[4];
+  /* chroma search */
+  int c_best_mode; uint32_t c_best_dist; double c_best_cost;
+  uint32_t c_dist;
+  int uni[8];
+};
+
+struct Env { Chain *C; Scratch *G; Shared *S; int cur_ctu, slice_start; };
+
+/* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
+struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
+
+/* ======================================================================================== */
+/* small helpers                                                                            */
+/* ======================================================================================== */
+FCU_DEV int part_x(int z) { return (k_z2r[z] & 15) << 2; }
+FCU_DEV int part_y(int z) { return (k_z2r[z] >> 4) << 2; }
+FCU_DEV int zidx_of(int lx, int ly) { return k_r2z[((ly & 63) >> 2) * 16 + ((lx & 63) >> 2)]; }
+FCU_DEV int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+FCU_DEV int iabs(int v) { return v < 0 ? -v : v; }
+FCU_DEV int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+FCU_DEV int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+FCU_DEV uint8_t *yuv_plane(Yuv *b, int comp) { return comp == 0 ? b->y : (comp == 1 ? b->u : b->v); }
+FCU_DEV double rd_cost(const Params &p, uint32_t bits, uint32_t dist)          /* TComRdCost::calcRdCost, TComRdCost.cpp:56-123 */
+{ return FCU_FLOOR((double)dist + ((double)bits * p.lambda) + 0.5); }
+
+FCU_DEV void tu_root(TU &t, int depth)
+{
+  t.log2 = 6 - depth; t.tr_depth = 0; t.part = 0; t.nparts = NPART >> (2 * depth); t.x = t.y = 0; t.off_y = 0;
+  t.cw = t.cwo = (CTU >> depth) >> 1; t.cx = t.cy = 0; t.c_tr_depth = 0; t.c_code_all = 1; t.off_c = 0;
+}
+FCU_DEV void tu_child(TU &c, const TU &p, int i, int processLast)
+{
+  const int s = 1 << (p.log2 - 1);
+  c.log2 = p.log2 - 1; c.tr_depth = p.tr_depth + 1;
+  c.nparts = p.nparts >> 2; if (c.nparts < 1) c.nparts = 1;
+  c.part = p.part + i * c.nparts;
+  c.x = p.x + (i & 1) * s; c.y = p.y + (i >> 1) * s; c.off_y = p.off_y + i * s * s;
+  const int pw = p.cwo;
+  if ((pw >> 1) >= 4) {
+    const int cs = pw >> 1;
+    c.cw = c.cwo = cs; c.c_code_all = 1; c.c_tr_depth = p.c_tr_depth + 1;
+    c.cx = p.cx + (i & 1) * cs; c.cy = p.cy + (i >> 1) * cs; c.off_c = p.off_c + i * cs * cs;
+  } else {
+    c.cwo = pw; c.c_code_all = 0; c.c_tr_depth = p.c_tr_depth; c.cx = p.cx; c.cy = p.cy; c.off_c = p.off_c;
+    c.cw = (processLast ? (i == 3) : (i == 0)) ? pw : 0;
+  }
+}
+FCU_DEV int tu_part_c(const TU &t) { return t.c_code_all ? t.part : (t.part & ~3); }
+FCU_DEV int tu_nparts_c(const TU &t) { return t.c_code_all ? t.nparts : t.nparts * 4; }
+
+/* ======================================================================================== */
+/* CABAC bit counter -- per-lane callable (TEncBinCoderCABACCounter.cpp:59-136)              */
+/* ======================================================================================== */
+FCU_DEV void cab_init(Cabac *c, int qp)            /* ContextModel::init, ContextModel.cpp:56-65 */
+{
+  if (qp < 0) qp = 0; if (qp > 51) qp = 51;
+  for (int i = 0; i < NCTX; i++) {
+    int iv = k_ctx_init_I[i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
+    int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    int mps = st >= 64;
+    c->ctx[i] = (uint8_t)(((mps ? (st - 64) : (63 - st)) << 1) + mps);
+  }
+  c->frac = 0; c->bins = 0; c->pad_ = 0;
+}
+FCU_DEV void cab_copy(Cabac *d, const Cabac *s, int lane)     /* cooperative copy: 44 dwords */
+{ const uint32_t *a = (const uint32_t *)s; uint32_t *b = (uint32_t *)d; if (lane < (int)(sizeof(Cabac) / 4)) b[lane] = a[lane]; }
+FCU_DEV void cab_copy1(Cabac *d, const Cabac *s)              /* single-lane copy */
+{ const uint32_t *a = (const uint32_t *)s; uint32_t *b = (uint32_t *)d; for (int i = 0; i < (int)(sizeof(Cabac) / 4); i++) b[i] = a[i]; }
+FCU_DEV void cab_bin(Cabac *c, int bin, int ctx)
+{
+  uint8_t s = c->ctx[ctx];
+  c->bins++;
+  c->frac += (uint64_t)k_entropy_bits[s ^ bin];
+  c->ctx[ctx] = k_next_state[s * 2 + bin];
+}
+FCU_DEV void cab_ep(Cabac *c, int n) { c->bins += (uint32_t)n; c->frac += (uint64_t)32768 * (uint64_t)n; }
+FCU_DEV void cab_trm(Cabac *c, int bin) { c->bins++; c->frac += (uint64_t)k_entropy_bits[126 ^ bin]; }
+FCU_DEV void cab_reset_bits(Cabac *c) { c->frac &= 32767; c->bins = 0; }
+FCU_DEV uint32_t cab_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
+FCU_DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return k_entropy_bits[c->ctx[ctx] ^ bin]; }
+
+/* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
+FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
+{
+  if (log2 > (comp ? 2 : 3)) return 0;
+  if (iabs(dir - VER) <= 4) return 1;
+  if (iabs(dir - HOR) <= 4) return 2;
+  return 0;
+}
+FCU_DEV int pattern_sig_ctx(const uint8_t *cg, int cgx, int cgy, int wg)       /* TComTrQuant.cpp:2584-2609 */
+{
+  if (wg <= 1) return 0;
+  int r = 0, l = 0;
+  if (cgx < wg - 1) r = cg[cgy * wg + cgx + 1] != 0;
+  if (cgy < wg - 1) l = cg[(cgy + 1) * wg + cgx] != 0;
+  return r + (l << 1);
+}
+FCU_DEV int sig_cg_ctx(const uint8_t *cg, int cgx, int cgy, int wg)            /* TComTrQuant.cpp:2949-2969 */
+{
+  int r = 0, l = 0;
+  if (cgx < wg - 1) r = cg[cgy * wg + cgx + 1] != 0;
+  if (cgy < wg - 1) l = cg[(cgy + 1) * wg + cgx] != 0;
+  return (r + l) != 0;
+}
+FCU_DEV int first_sig_ctx(int log2, int scan, int ch)                          /* TComChromaFormat.cpp:129-155 */
+{ if (log2 == 2) return 0; if (log2 == 3) return 9 + ((scan != 0 && !ch) ? 6 : 0); return ch ? 12 : 21; }
+FCU_DEV int sig_ctx_inc(int pattern, int first, int pos, int log2, int ch)     /* TComTrQuant.cpp:2619-2718 */
+{
+  const int py = pos >> log2, px = pos - (py << log2);
+  if (px + py == 0) return 0;
+  int offset;
+  if (log2 == 2) offset = k_ctx_ind_map4x4[4 * py + px];
+  else {
+    int cnt; const int xs = px & 3, ys = py & 3;
+    if (pattern == 0) { int t = xs + ys; cnt = (t >= 3) ? 0 : ((t >= 1) ? 1 : 2); }
+    else if (pattern == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
+    else if (pattern == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
+    else cnt = 2;
+    offset = ((((px >> 2) + (py >> 2)) > 0) ? (ch ? 0 : 3) : 0) + cnt;
+  }
+  return first + offset;
+}
+FCU_DEV void code_coef_remain(Cabac *c, uint32_t symbol, uint32_t rparam)      /* TEncSbac.cpp:338-391 */
+{
+  int code = (int)symbol;
+  if (code < (3 << rparam)) { cab_ep(c, (int)(((uint32_t)code >> rparam) + 1)); cab_ep(c, (int)rparam); }
+  else {
+    uint32_t length = rparam;
+    code -= 3 << rparam;
+    while (code >= (1 << length)) code -= 1 << (length++);
+    cab_ep(c, (int)(3 + length + 1 - rparam)); cab_ep(c, (int)length);
+  }
+}
+/* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535 */
+FCU_DEV void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P)
+{
+  const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
+  int numSig = 0;
+  for (int i = 0; i < n2; i++) numSig += coef[i] != 0;
+  if (numSig == 0) return;                                    /* never called on empty TUs */
+  if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
+  const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
+  const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
+  uint8_t cgflag[64];
+  for (int i = 0; i < wg * wg; i++) cgflag[i] = 0;
+  int scanPosLast = -1, posLast;
+  do {
+    posLast = scan[++scanPosLast];
+    if (coef[posLast] != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag[wg * (py >> 2) + (px >> 2)] = 1; numSig--; }
+  } while (numSig > 0);
+  {
+    int py = posLast >> log2, px = posLast - (py << log2);
+    if (scanType == 2) { int t = px; px = py; py = t; }
+    const int gx = k_group_idx[px], gy = k_group_idx[py], cc = log2 - 2;
+    const int off = ch ? 0 : (cc * 3 + ((cc + 1) >> 2)), sh = ch ? cc : ((cc + 3) >> 2);
+    const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = k_group_idx[N - 1];
+    int k;
+    for (k = 0; k < gx; k++) cab_bin(c, 1, bx + (k >> sh));
+    if (gx < gmax) cab_bin(c, 0, bx + (k >> sh));
+    for (k = 0; k < gy; k++) cab_bin(c, 1, by + (k >> sh));
+    if (gy < gmax) cab_bin(c, 0, by + (k >> sh));
+    if (gx > 3) cab_ep(c, (gx - 2) >> 1);
+    if (gy > 3) cab_ep(c, (gy - 2) >> 1);
+  }
+  const int baseCG = CTX_SIGCG + (ch ? 2 : 0), baseSig = CTX_SIG + (ch ? 28 : 0), lastSet = scanPosLast >> 4;
+  uint32_t c1 = 1, goRice;
+  int scanPosSig = scanPosLast;
+  for (int sub = lastSet; sub >= 0; sub--) {
+    int numNonZero = 0; const int subPos = sub << 4;
+    goRice = 0;
+    int absCoeff[16], lastNZ = -1, firstNZ = 16, escape = 0;
+    if (scanPosSig == scanPosLast) { absCoeff[0] = iabs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
+    const int cgpos = scanCG[sub], cgy = cgpos / wg, cgx = cgpos - cgy * wg;
+    if (sub == lastSet || sub == 0) cgflag[cgpos] = 1;
+    else cab_bin(c, cgflag[cgpos] != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
+    if (cgflag[cgpos]) {
+      const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
+      for (; scanPosSig >= subPos; scanPosSig--) {
+        const int blk = scan[scanPosSig], sig = coef[blk] != 0;
+        if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, baseSig + sig_ctx_inc(pattern, firstSig, blk, log2, ch));
+        if (sig) { absCoeff[numNonZero++] = iabs(coef[blk]); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
+      }
+    } else scanPosSig = subPos - 1;
+    if (numNonZero > 0) {
+      const int signHidden = (lastNZ - firstNZ >= 4);
+      const int ctxSet = (ch ? 4 : 0) + ((!ch && sub > 0) ? 2 : 0) + (c1 == 0);
+      c1 = 1;
+      const int baseOne = CTX_ONE + 4 * ctxSet, numC1 = numNonZero < 8 ? numNonZero : 8;
+      int firstC2 = -1;
+      for (int idx = 0; idx < numC1; idx++) {
+        const int sym = absCoeff[idx] > 1;
+        cab_bin(c, sym, baseOne + (int)c1);
+        if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
+        else if (c1 < 3 && c1 > 0) c1++;
+      }
+      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; cab_bin(c, sym, CTX_ABS + ctxSet); if (sym) escape = 1; }
+      escape = escape || (numNonZero > 8);
+      cab_ep(c, (P.sign_hiding && signHidden) ? numNonZero - 1 : numNonZero);
+      int firstCoeff2 = 1;
+      if (escape)
+        for (int idx = 0; idx < numNonZero; idx++) {
+          const int base = (idx < 8) ? (2 + firstCoeff2) : 1;
+          if (absCoeff[idx] >= base) {
+            code_coef_remain(c, (uint32_t)(absCoeff[idx] - base), goRice);
+            if (absCoeff[idx] > (3 << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+          }
+          if (absCoeff[idx] >= 2) firstCoeff2 = 0;
+        }
+    }
+  }
+}
+
+/* ======================================================================================== */
+/* RDOQ -- per-lane callable (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:2033-2573)     */
+/* ======================================================================================== */
+struct RdoqBuf { double *cc, *cs, *c0; int32_t *up, *dn, *sd, *du; };
+
+FCU_DEV int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
+{                                                          /* xGetICRate, TComTrQuant.cpp:2807-2881 */
+  int rate = 32768;
+  const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+  if (absLevel >= baseLevel) {
+    uint32_t symbol = absLevel - baseLevel, length;
+    if (symbol < (3u << goRice)) { length = symbol >> goRice; rate += (int)((length + 1 + goRice) << 15); }
+    else {
+      length = goRice; symbol = symbol - (3u << goRice);
+      while (symbol >= (1u << length)) symbol -= (1u << (length++));
+      rate += (int)((3 + length + 1 - goRice + length) << 15);
+    }
+    if (c1Idx < 8) { rate += ctx_bits(c, ctxOne, 1); if (c2Idx < 1) rate += ctx_bits(c, ctxAbs, 1); }
+  } else if (absLevel == 1) rate += ctx_bits(c, ctxOne, 0);
+  else if (absLevel == 2) { rate += ctx_bits(c, ctxOne, 1); rate += ctx_bits(c, ctxAbs, 0); }
+  else rate = 0;
+  return rate;
+}
+FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
+                             int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, int ctxOne, int ctxAbs,
+                             uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last)
+{                                                          /* xGetCodedLevel, TComTrQuant.cpp:2738-2794 */
+  double currCostSig = 0; uint32_t bestAbs = 0;
+  if (!last && maxAbsLevel < 3) {
+    *codedCostSig = lambda * (double)ctx_bits(c, ctxSig, 0);
+    *codedCost = *codedCost0 + *codedCostSig;
+    if (maxAbsLevel == 0) return bestAbs;
+  } else *codedCost = FCU_MAX_DOUBLE;
+  if (!last) currCostSig = lambda * (double)ctx_bits(c, ctxSig, 1);
+  const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
+  for (int a = (int)maxAbsLevel; a >= (int)minAbs; a--) {
+    double err = (double)(levelDouble - ((int32_t)a << qbits));
+    double cost = err * err * errScale + lambda * (double)ic_rate(c, (uint32_t)a, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+    cost += currCostSig;
+    if (cost < *codedCost) { bestAbs = (uint32_t)a; *codedCost = cost; *codedCostSig = currCostSig; }
+  }
+  return bestAbs;
+}
+/* `c` is the coder whose contexts estBit() would snapshot (TEncSbac.cpp:1722-1956); cbfCtx
+ * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset). Returns uiAbsSum. */
+FCU_DEV int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
+                 const Params &P, const RdoqBuf &rb)
+{
+  const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
+  const int qp = comp ? P.qp_c : P.qp, per = qp / 6, rem = qp % 6;
+  const int tshift = 15 - 8 - log2, qbits = 14 + per + tshift;
+  const double lambda = P.rdoq_lambda[comp];
+  const int qcoef = k_quant_scales[rem];
+  const double errScale = P.err_scale[ch][log2 - 2];
+  double *costCoeff = rb.cc, *costSig = rb.cs, *costCoeff0 = rb.c0;
+  int32_t *rateIncUp = rb.up, *rateIncDown = rb.dn, *sigRateDelta = rb.sd, *deltaU = rb.du;
+  for (int i = 0; i < n2; i++) { costCoeff[i] = 0; costSig[i] = 0; rateIncUp[i] = 0; rateIncDown[i] = 0; sigRateDelta[i] = 0; deltaU[i] = 0; }
+  const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
+  const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
+  const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
+  double costCGSig[64]; uint8_t cgflag[64];
+  for (int i = 0; i < wg * wg; i++) { costCGSig[i] = 0; cgflag[i] = 0; }
+  int cgLastScanPos = -1; uint32_t ctxSet = 0; int c1 = 1, c2 = 0;
+  double baseCost = 0, blockUncodedCost = 0;
+  int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
+  const int cgNum = n2 >> 4; int absSum = 0;
+
+  for (int cgScanPos = cgNum - 1; cgScanPos >= 0; cgScanPos--) {
+    const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
+    double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
+    const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
+    for (int posInCG = 15; posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
+      const long long tmpLevel = (long long)iabs(src[blk]) * qcoef;
+      const long long lim = 2147483647LL - (1LL << (qbits - 1));
+      const int32_t levelDouble = (int32_t)(tmpLevel < lim ? tmpLevel : lim);
+      uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
+      if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
+      const double err = (double)levelDouble;
+      costCoeff0[scanPos] = err * err * errScale;
+      blockUncodedCost += costCoeff0[scanPos];
+      dst[blk] = (int16_t)maxAbsLevel;
+      if (maxAbsLevel > 0 && lastScanPos < 0) {
+        lastScanPos = scanPos;
+        ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && (scanPos >> 4) > 0) ? 2 : 0));
+        cgLastScanPos = cgScanPos;
+      }
+      if (lastScanPos >= 0) {
+        uint32_t level;
+        const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1, absCtx = CTX_ABS + (int)ctxSet + c2;
+        if (scanPos == lastScanPos)
+          level = coded_level(c, lambda, &costCoeff[scanPos], &costCoeff0[scanPos], &costSig[scanPos], levelDouble, maxAbsLevel,
+                              sigOff, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 1);
+        else {
+          const int ctxSig = sigOff + sig_ctx_inc(pattern, firstSig, blk, log2, ch);
+          level = coded_level(c, lambda, &costCoeff[scanPos], &costCoeff0[scanPos], &costSig[scanPos], levelDouble, maxAbsLevel,
+                              ctxSig, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 0);
+          sigRateDelta[blk] = ctx_bits(c, ctxSig, 1) - ctx_bits(c, ctxSig, 0);
+        }
+        deltaU[blk] = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
+        if (level > 0) {
+          const int rateNow = ic_rate(c, level, oneCtx, absCtx, goRice, c1Idx, c2Idx);
+          rateIncUp[blk] = ic_rate(c, level + 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
+          rateIncDown[blk] = ic_rate(c, level - 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
+        } else rateIncUp[blk] = ctx_bits(c, oneCtx, 0);
+        dst[blk] = (int16_t)level;
+        baseCost += costCoeff[scanPos];
+        const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+        if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
+        if (level >= 1) c1Idx++;
+        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
+        else if (c1 < 3 && c1 > 0 && level) c1++;
+        if ((scanPos % 16 == 0) && scanPos > 0) {
+          ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && ((scanPos - 1) >> 4) > 0) ? 2 : 0) + (c1 == 0));
+          c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+        }
+      } else baseCost += costCoeff0[scanPos];
+      rdSigCost += costSig[scanPos];
+      if (posInCG == 0) rdSigCost0 = costSig[scanPos];
+      if (dst[blk]) {
+        cgflag[cgBlk] = 1;
+        rdCodedLevelandDist += costCoeff[scanPos] - costSig[scanPos];
+        rdUncodedDist += costCoeff0[scanPos];
+        if (posInCG != 0) nnzBeforePos0++;
+      }
+    }
+    if (cgLastScanPos >= 0) {
+      if (cgScanPos) {
+        if (cgflag[cgBlk] == 0) {
+          const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
+          baseCost += lambda * (double)ctx_bits(c, ctxSig, 0) - rdSigCost;
+          costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
+        } else if (cgScanPos < cgLastScanPos) {
+          if (nnzBeforePos0 == 0) { baseCost -= rdSigCost0; rdSigCost -= rdSigCost0; }
+          double costZeroCG = baseCost;
+          const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
+          baseCost += lambda * (double)ctx_bits(c, ctxSig, 1);
+          costZeroCG += lambda * (double)ctx_bits(c, ctxSig, 0);
+          costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 1);
+          costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
+          if (costZeroCG < baseCost) {
+            cgflag[cgBlk] = 0; baseCost = costZeroCG;
+            costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
+            for (int posInCG = 15; posInCG >= 0; posInCG--) {
+              const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
+              if (dst[blk]) { dst[blk] = 0; costCoeff[scanPos] = costCoeff0[scanPos]; costSig[scanPos] = 0; }
+            }
+          }
+        }
+      } else cgflag[cgBlk] = 1;
+    }
+  }
+  if (lastScanPos < 0) return 0;
+
+  double bestCost; int bestLastIdxP1 = 0;
+  bestCost = blockUncodedCost + lambda * (double)ctx_bits(c, cbfCtx, 0);
+  baseCost += lambda * (double)ctx_bits(c, cbfCtx, 1);
+  int lastXBits[10], lastYBits[10];                         /* estLastSignificantPositionBit, TEncSbac.cpp:1863-1923 */
+  {
+    const int cc = log2 - 2, off = ch ? 0 : (cc * 3 + ((cc + 1) >> 2)), sh = ch ? cc : ((cc + 3) >> 2);
+    const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = k_group_idx[N - 1];
+    int k, bitsX = 0, bitsY = 0;
+    for (k = 0; k < gmax; k++) { lastXBits[k] = bitsX + ctx_bits(c, bx + (k >> sh), 0); bitsX += ctx_bits(c, bx + (k >> sh), 1); }
+    lastXBits[k] = bitsX;
+    for (k = 0; k < gmax; k++) { lastYBits[k] = bitsY + ctx_bits(c, by + (k >> sh), 0); bitsY += ctx_bits(c, by + (k >> sh), 1); }
+    lastYBits[k] = bitsY;
+  }
+  int foundLast = 0;
+  for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
+    const int cgBlk = scanCG[cgScanPos];
+    baseCost -= costCGSig[cgScanPos];
+    if (cgflag[cgBlk]) {
+      for (int posInCG = 15; posInCG >= 0; posInCG--) {
+        const int scanPos = cgScanPos * 16 + posInCG;
+        if (scanPos > lastScanPos) continue;
+        const int blk = scan[scanPos];
+        if (dst[blk]) {
+          const int py = blk >> log2, px = blk - (py << log2);
+          const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
+          const int gx = k_group_idx[ax], gy = k_group_idx[ay];
+          double r = (double)(lastXBits[gx] + lastYBits[gy]);              /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
+          if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
+          if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
+          const double costLast = lambda * r;
+          const double totalCost = baseCost + costLast - costSig[scanPos];
+          if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
+          if (dst[blk] > 1) { foundLast = 1; break; }
+          baseCost -= costCoeff[scanPos]; baseCost += costCoeff0[scanPos];
+        } else baseCost -= costSig[scanPos];
+      }
+      if (foundLast) break;
+    }
+  }
+  for (int sp = 0; sp < bestLastIdxP1; sp++) {
+    const int blk = scan[sp]; const int level = dst[blk];
+    absSum += level;
+    dst[blk] = (int16_t)((src[blk] < 0) ? -level : level);
+  }
+  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[scan[sp]] = 0;
+
+  if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
+    const long long rdFactor = P.rd_factor[ch];
+    int lastCG = -1;
+    for (int subSet = (n2 - 1) >> 4; subSet >= 0; subSet--) {
+      const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
+      for (n = 15; n >= 0; --n) if (dst[scan[n + subPos]]) { lastNZ = n; break; }
+      for (n = 0; n < 16; n++) if (dst[scan[n + subPos]]) { firstNZ = n; break; }
+      for (n = firstNZ; n <= lastNZ; n++) sum += dst[scan[n + subPos]];
+      if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+      if (lastNZ - firstNZ >= 4) {
+        const uint32_t signbit = dst[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+        if (signbit != (uint32_t)(sum & 1)) {
+          long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
+          int minPos = -1, finalChange = 0, curChange = 0;
+          for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
+            const int blk = scan[n + subPos];
+            if (dst[blk] != 0) {
+              const long long costUp = rdFactor * (-deltaU[blk]) + rateIncUp[blk];
+              long long costDown = rdFactor * (deltaU[blk]) + rateIncDown[blk] - ((iabs(dst[blk]) == 1) ? sigRateDelta[blk] : 0);
+              if (lastCG == 1 && lastNZ == n && iabs(dst[blk]) == 1) costDown -= (4 << 15);
+              if (costUp < costDown) { curCost = costUp; curChange = 1; }
+              else { curChange = -1; if (n == firstNZ && iabs(dst[blk]) == 1) curCost = 0x7fffffffffffffffLL; else curCost = costDown; }
+            } else {
+              curCost = rdFactor * (-(long long)(iabs(deltaU[blk]))) + (1 << 15) + rateIncUp[blk] + sigRateDelta[blk];
+              curChange = 1;
+              if (n < firstNZ) { const uint32_t thissign = src[blk] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
+            }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = blk; }
+          }
+          if (dst[minPos] == 32767 || dst[minPos] == -32768) finalChange = -1;
+          if (src[minPos] >= 0) dst[minPos] = (int16_t)(dst[minPos] + finalChange); else dst[minPos] = (int16_t)(dst[minPos] - finalChange);
+        }
+      }
+      if (lastCG == 1) lastCG = 0;
+    }
+  }
+  return absSum;
+}
+
+/* ======================================================================================== */
+/* intra prediction: closed form per pixel (TComPrediction.cpp:183-496,755-841)              */
+/* ======================================================================================== */
+FCU_DEV int use_filtered_ref(int mode, int log2, int isLuma)               /* TComPattern.cpp:523-548 */
+{
+  if (!isLuma || mode == DC) return 0;
+  const int d1 = iabs(mode - HOR), d2 = iabs(mode - VER);
+  return (d1 < d2 ? d1 : d2) > k_filter_thr[log2 - 2];
+}
+/* ref[0..4N]: bottom-left ... corner(2N) ... top-right.  corner[+i] = top(i-1), corner[-i] = left(i-1) */
+FCU_DEV int pred_pixel(const uint8_t *ref, int log2, int mode, int isLuma, int dc, int x, int y)
+{
+  const int N = 1 << log2;
+  const uint8_t *corner = ref + 2 * N;
+  if (mode == PLANAR)
+    return ((N - 1 - x) * corner[-1 - y] + (x + 1) * corner[1 + N] + (N - 1 - y) * corner[1 + x] + (y + 1) * corner[-1 - N] + N) >> (log2 + 1);
+  if (mode == DC) {
+    int v = dc;
+    if (isLuma && N <= 16) {
+      if (x == 0 && y == 0) v = (corner[1] + corner[-1] + 2 * dc + 2) >> 2;
+      else if (y == 0) v = (corner[1 + x] + 3 * dc + 2) >> 2;
+      else if (x == 0) v = (corner[-1 - y] + 3 * dc + 2) >> 2;
+    }
+    return v;
+  }
+  const int isVer = mode >= 18;
+  const int angMode = isVer ? mode - VER : -(mode - HOR);
+  const int absAng = iabs(angMode), angle = (angMode < 0 ? -1 : 1) * k_ang[absAng], invAngle = k_inv_ang[absAng];
+  const int px = isVer ? x : y, py = isVer ? y : x, ms = isVer ? 1 : -1;   /* main array direction from the corner */
+  if (angle == 0) {
+    int v = corner[ms * (px + 1)];
+    if (isLuma && N <= 16 && px == 0) v = clip8(v + ((corner[-ms * (py + 1)] - corner[0]) >> 1));
+    return v;
+  }
+  const int deltaPos = (py + 1) * angle, di = deltaPos >> 5, df = deltaPos & 31;
+  const int i0 = px + di + 1;
+  int r0, r1;
+  { int i = i0; r0 = (i >= 0) ? corner[ms * i] : corner[-ms * ((128 + (-i) * invAngle) >> 8)]; }
+  if (!df) return r0;
+  { int i = i0 + 1; r1 = (i >= 0) ? corner[ms * i] : corner[-ms * ((128 + (-i) * invAngle) >> 8)]; }
+  return ((32 - df) * r0 + df * r1 + 16) >> 5;
+}
+
+/* z-scan availability (H.265 6.4.1 == getPULeft/Above/.../BelowLeftAdi, TComDataCU.cpp:1071-1390) */
+FCU_DEV int unit_available(const Env &E, int lx, int ly, int cx, int cy)
+{
+  const Params &P = E.C->p;
+  if (lx < 0 || ly < 0 || lx >= P.width || ly >= P.height) return 0;
+  const int ctuN = (ly >> 6) * E.C->w_ctu + (lx >> 6), ctuC = (cy >> 6) * E.C->w_ctu + (cx >> 6);
+  if (ctuN < E.slice_start) return 0;
+  if (ctuN < ctuC) return 1;
+  if (ctuN > ctuC) return 0;
+  return zidx_of(lx, ly) < zidx_of(cx, cy);
+}
+
+/* Reference samples of a block (initAdiPatternChType + fillReferenceSamples + smoothing,
+ * TComPattern.cpp:104-521) -> S->ref (unfiltered), S->reff (filtered, luma only), S->dc. */
+FCU_DEV void build_ref(const Env &E, int comp, int px, int py, int log2, int wantFilt)
+{
+  Shared *S = E.S;
+  const int N = 1 << log2, sh = comp ? 1 : 0, unit = 4 >> sh, total = 4 * N + 1;
+  const int lx0 = px << sh, ly0 = py << sh;
+  const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
+  uint8_t *ref = S->ref, *avail = (uint8_t *)S->colsum;    /* availability flags staged in colsum (>= 257 bytes) */
+  FCU_FOR_LANES {
+    for (int i = lane; i < total; i += 64) {
+      int a, v = 0;
+      if (i < 2 * N) { const int y = 2 * N - 1 - i; a = unit_available(E, lx0 - 4, ((py + y) / unit * unit) << sh, lx0, ly0); if (a) v = rec[(py + y) * stride + px - 1]; }
+      else if (i == 2 * N) { a = unit_available(E, lx0 - 4, ly0 - 4, lx0, ly0); if (a) v = rec[(py - 1) * stride + px - 1]; }
+      else { const int x = i - 2 * N - 1; a = unit_available(E, ((px + x) / unit * unit) << sh, ly0 - 4, lx0, ly0); if (a) v = rec[(py - 1) * stride + px + x]; }
+      avail[i] = (uint8_t)a; ref[i] = (uint8_t)v;
+    }
+  }
+  /* substitution: every unavailable sample takes the nearest available one below it in walk
+   * order, or (for the leading run) the first available one */
+  FCU_FOR_LANES {
+    for (int i = lane; i < total; i += 64) {
+      if (!avail[i]) {
+        int j = i - 1;
+        while (j >= 0 && !avail[j]) j--;
+        if (j < 0) { j = i + 1; while (j < total && !avail[j]) j++; }
+        S->reff[i] = (j < total) ? ref[j] : 128;            /* staged in reff, merged below */
+      }
+    }
+  }
+  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) ref[i] = S->reff[i]; }
+  FCU_FOR_LANES {
+    if (lane == 0) { int sum = 0; for (int i = 0; i < N; i++) sum += ref[2 * N + 1 + i] + ref[2 * N - 1 - i]; S->dc = (sum + N) >> (log2 + 1); }
+    if (wantFilt) {
+      int strong = 0;
+      if (comp == 0 && E.C->p.strong_smoothing && N >= 32) {
+        const int bl = ref[0], tl = ref[2 * N], tr = ref[4 * N];
+        strong = (iabs(bl + tl - 2 * ref[N]) < 8) && (iabs(tl + tr - 2 * ref[3 * N]) < 8);
+      }
+      for (int i = lane; i < total; i += 64) {
+        int v;
+        if (i == 0 || i == 4 * N) v = ref[i];
+        else if (strong) {
+          const int bl = ref[0], tl = ref[2 * N], tr = ref[4 * N];
+          if (i < 2 * N) v = ((2 * N - i) * bl + i * tl + N) >> (log2 + 1);
+          else if (i == 2 * N) v = tl;
+          else { const int k = i - 2 * N; v = ((2 * N - k) * tl + k * tr + N) >> (log2 + 1); }
+        } else v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
+        S->reff[i] = (uint8_t)v;
+      }
+    }
+  }
+}
+
+/* ======================================================================================== */
+/* transforms: one output coefficient per call (xTrMxN / xITrMxN, TComTrQuant.cpp:860-987;    */
+/* the partial butterflies are exact factorizations of these products)                       */
+/* ======================================================================================== */
+FCU_DEV int tmat(int log2, int useDst, int k, int n) { return (useDst && log2 == 2) ? k_dst4[k * 4 + n] : k_dct[k_dct_off[log2 - 2] + (k << log2) + n]; }
+/* stage 1: tmp[k*N+y] from resi rows ; stage 2: coef[k2*N+k1] from tmp */
+FCU_DEV int32_t fwd1(const int16_t *resi, int log2, int useDst, int idx)
+{ const int N = 1 << log2, k = idx >> log2, y = idx & (N - 1), s1 = log2 - 1; int32_t s = 0; for (int n = 0; n < N; n++) s += tmat(log2, useDst, k, n) * resi[y * N + n]; return (s + (1 << (s1 - 1))) >> s1; }
+FCU_DEV int32_t fwd2(const int32_t *tmp, int log2, int useDst, int idx)
+{ const int N = 1 << log2, k2 = idx >> log2, k1 = idx & (N - 1), s2 = log2 + 6; int32_t s = 0; for (int y = 0; y < N; y++) s += tmat(log2, useDst, k2, y) * tmp[k1 * N + y]; return (s + (1 << (s2 - 1))) >> s2; }
+/* inverse stage 1: tmp[kh*N+y] from dequantised coef ; stage 2: resi[y*N+x] */
+FCU_DEV int32_t inv1(const int32_t *coef, int log2, int useDst, int idx)
+{ const int N = 1 << log2, kh = idx >> log2, y = idx & (N - 1); int32_t s = 0; for (int kv = 0; kv < N; kv++) s += tmat(log2, useDst, kv, y) * coef[kv * N + kh]; return clip3i(-32768, 32767, (s + 64) >> 7); }
+FCU_DEV int32_t inv2(const int32_t *tmp, int log2, int useDst, int idx)
+{ const int N = 1 << log2, y = idx >> log2, x = idx & (N - 1); int32_t s = 0; for (int kh = 0; kh < N; kh++) s += tmat(log2, useDst, kh, x) * tmp[kh * N + y]; return clip3i(-32768, 32767, (s + 2048) >> 12); }
+FCU_DEV int32_t dequant1(int q, int log2, int qp)          /* xDeQuant flat, TComTrQuant.cpp:1242-1352 */
+{
+  const int per = qp / 6, rem = qp % 6, rs = 6 - ((15 - 8 - log2) + per), scale = k_inv_quant_scales[rem];
+  int tbd = 32 + rs - 7; if (tbd > 16) tbd = 16;
+  const int c = clip3i(-(1 << (tbd - 1)), (1 << (tbd - 1)) - 1, q);
+  if (rs > 0) return clip3i(-32768, 32767, (c * scale + (1 << (rs - 1))) >> rs);
+  return clip3i(-32768, 32767, (c * scale) << (-rs));
+}
+
+/* ======================================================================================== */
+/* neighbour decisions (MPM, split context)                                                  */
+/* ======================================================================================== */
+FCU_DEV int inside_cu(const CuObj *cu, int lx, int ly) { const int s = CTU >> cu->depth_cu; return lx >= cu->x && lx < cu->x + s && ly >= cu->y && ly < cu->y + s; }
+FCU_DEV int nb_depth(const Env &E, const CuObj *cu, int lx, int ly)
+{ return inside_cu(cu, lx, ly) ? cu->depth[zidx_of(lx, ly) - cu->zidx] : E.C->out[(ly >> 6) * E.C->w_ctu + (lx >> 6)].depth[zidx_of(lx, ly)]; }
+FCU_DEV int nb_luma_dir(const Env &E, const CuObj *cu, int lx, int ly)
+{
+  if (inside_cu(cu, lx, ly)) { const int p = zidx_of(lx, ly) - cu->zidx; return cu->pred_mode[p] == MODE_INTRA ? cu->intra_dir[0][p] : DC; }
+  const fcu_ctu_out *c = &E.C->out[(ly >> 6) * E.C->w_ctu + (lx >> 6)]; const int p = zidx_of(lx, ly);
+  return c->pred_mode[p] == MODE_INTRA ? c->intra_dir[0][p] : DC;
+}
+FCU_DEV int left_ctu_ok(const Env &E, int lx, int ly) { if (lx == 0) return 0; if (lx & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - 1 >= E.slice_start; }
+FCU_DEV int above_ctu_ok(const Env &E, int lx, int ly) { if (ly == 0) return 0; if (ly & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - E.C->w_ctu >= E.slice_start; }
+/* getIntraDirPredictor, TComDataCU.cpp:1542-1624 */
+FCU_DEV int intra_dir_predictor(const Env &E, const CuObj *cu, int part, int *preds)
+{
+  const int z = cu->zidx + part, lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
+  const int left = left_ctu_ok(E, lx, ly) ? nb_luma_dir(E, cu, lx - 1, ly) : DC;
+  const int above = ((ly & 63) != 0) ? nb_luma_dir(E, cu, lx, ly - 1) : DC;
+  if (left == above) {
+    if (left > 1) { preds[0] = left; preds[1] = ((left + 29) % 32) + 2; preds[2] = ((left - 1) % 32) + 2; }
+    else { preds[0] = PLANAR; preds[1] = DC; preds[2] = VER; }
+    return 1;
+  }
+  preds[0] = left; preds[1] = above;
+  preds[2] = (left && above) ? PLANAR : ((left + above) < 2 ? VER : DC);
+  return 2;
+}
+FCU_DEV int min_tu_log2_in_cu(int depth, int partSize)      /* getQuadtreeTULog2MinSizeInCU, TComDataCU.cpp:1658-1686 */
+{
+  const int log2Cb = 6 - depth, split = partSize == SIZE_NxN;
+  if (log2Cb < LOG2_MINTU + TU_MAXDEPTH_INTRA - 1 + split) return LOG2_MINTU;
+  const int m = log2Cb - (TU_MAXDEPTH_INTRA - 1 + split);
+  return m > LOG2_MAXTU ? LOG2_MAXTU : m;
+}
+
+/* ---- syntax element coders (serial, any Cabac) ------------------------------------------ */
+FCU_DEV void code_split_flag(const Env &E, Cabac *c, const CuObj *cu, int part, int depth)   /* TEncSbac.cpp:613-628 */
+{
+  if (depth == MAXDEPTH) return;
+  const int z = cu->zidx + part, lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
+  int ctx = 0;
+  if (left_ctu_ok(E, lx, ly)) ctx += nb_depth(E, cu, lx - 1, ly) > depth;
+  if (above_ctu_ok(E, lx, ly)) ctx += nb_depth(E, cu, lx, ly - 1) > depth;
+  cab_bin(c, cu->depth[part] > depth, CTX_SPLIT + ctx);
+}
+/* codeIntraDirLumaAng for one PU with known MPM list (TEncSbac.cpp:643-696) */
+FCU_DEV void code_luma_dir_bits(Cabac *c, int dir, const int *preds)
+{
+  int predIdx = -1;
+  for (int i = 0; i < 3; i++) if (dir == preds[i]) predIdx = i;
+  cab_bin(c, predIdx != -1, CTX_INTRA_LUMA);
+  cab_ep(c, predIdx != -1 ? (predIdx ? 2 : 1) : 5);
+}
+FCU_DEV void code_intra_dir_luma(const Env &E, Cabac *c, const CuObj *cu, int part, int multiple)
+{
+  int preds[4][3], predIdx[4];
+  const int partNum = multiple ? (cu->part_size[part] == SIZE_NxN ? 4 : 1) : 1;
+  const int partOffset = (NPART >> (cu->depth[part] << 1)) >> 2;
+  for (int j = 0; j < partNum; j++) {
+    const int dir = cu->intra_dir[0][part + partOffset * j];
+    intra_dir_predictor(E, cu, part + partOffset * j, preds[j]);
+    predIdx[j] = -1;
+    for (int i = 0; i < 3; i++) if (dir == preds[j][i]) predIdx[j] = i;
+    cab_bin(c, predIdx[j] != -1, CTX_INTRA_LUMA);
+  }
+  for (int j = 0; j < partNum; j++) cab_ep(c, predIdx[j] != -1 ? (predIdx[j] ? 2 : 1) : 5);
+}
+FCU_DEV void code_intra_dir_chroma(Cabac *c, int dir)       /* TEncSbac.cpp:698-725 */
+{ if (dir == DM_CHROMA) cab_bin(c, 0, CTX_CHROMA_PRED); else { cab_bin(c, 1, CTX_CHROMA_PRED); cab_ep(c, 2); } }
+FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
+
+/* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
+FCU_DEV void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int bLuma, int bChroma)
+{
+  TU st[4]; int ci[4]; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU &tu = st[sp];
+    if (ci[sp] < 0) {
+      const int subdiv = cu->tr_idx[tu.part] > tu.tr_depth;
+      if (cu->part_size[0] == SIZE_NxN && tu.tr_depth == 0) { }
+      else if (tu.log2 > LOG2_MAXTU) { }
+      else if (tu.log2 == LOG2_MINTU) { }
+      else if (tu.log2 == min_tu_log2_in_cu(cu->depth[tu.part], cu->part_size[tu.part])) { }
+      else if (bLuma) cab_bin(c, subdiv, CTX_SUBDIV + 5 - tu.log2);
+      if (bChroma)
+        for (int comp = 1; comp < 3; comp++)
+          if (tu.c_code_all && (tu.tr_depth == 0 || ((cu->cbf[comp][tu.part] >> (tu.tr_depth - 1)) & 1))) {
+            const int lowest = tu.tr_depth + ((subdiv && !(tu.cw >= 8)) ? 1 : 0);
+            cab_bin(c, (cu->cbf[comp][tu_part_c(tu)] >> lowest) & 1, CTX_CBF_CHROMA + tu.tr_depth);
+          }
+      if (!subdiv) { if (bLuma) cab_bin(c, (cu->cbf[0][tu.part] >> tu.tr_depth) & 1, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0)); sp--; continue; }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+  (void)E;
+}
+FCU_DEV void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int comp, int realCoeff)
+{
+  TU st[4]; int ci[4]; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU &tu = st[sp];
+    if (ci[sp] < 0) {
+      if (!(cu->tr_idx[tu.part] > tu.tr_depth)) {
+        if (!(comp && tu.cw == 0) && ((cu->cbf[comp][tu.part] >> tu.tr_depth) & 1)) {
+          const int layer = LOG2_MAXTU - tu.log2;
+          const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
+          const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
+          const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
+          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p);
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+FCU_DEV void enc_intra_header(const Env &E, Cabac *c, const CuObj *cu, int trDepth, int part, int bLuma, int bChroma)
+{
+  if (bLuma) {
+    if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, cu->part_size[0] == SIZE_2Nx2N, CTX_PARTSIZE);
+    if (cu->part_size[0] == SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(E, c, cu, 0, 0); }
+    else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(E, c, cu, part, 0); }
+  }
+  if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
+}
+FCU_DEV uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &tu, int bLuma, int bChroma)
+{
+  cab_reset_bits(c);
+  enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
+  enc_subdiv_cbf_qt(E, c, cu, tu, bLuma, bChroma);
+  if (bLuma) enc_coeff_qt(E, c, cu, tu, 0, 0);
+  if (bChroma) { enc_coeff_qt(E, c, cu, tu, 1, 0); enc_coeff_qt(E, c, cu, tu, 2, 0); }
+  return cab_bits(c);
+}
+
+/* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
+FCU_DEV void encode_transform(const Env &E, Cabac *c, const CuObj *cu, int cuPart, const TU &root)
+{
+  TU st[4]; int ci[4]; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU &tu = st[sp];
+    if (ci[sp] < 0) {
+      const int part = cuPart + tu.part, trIdx = tu.tr_depth, subdiv = cu->tr_idx[part] > trIdx;
+      if (cu->part_size[part] == SIZE_NxN && trIdx == 0) { }
+      else if (tu.log2 > LOG2_MAXTU) { }
+      else if (tu.log2 == LOG2_MINTU) { }
+      else if (tu.log2 == min_tu_log2_in_cu(cu->depth[part], cu->part_size[part])) { }
+      else cab_bin(c, subdiv, CTX_SUBDIV + 5 - tu.log2);
+      const int first = trIdx == 0;
+      for (int comp = 1; comp < 3; comp++)
+        if (first || tu.c_code_all)
+          if (first || ((cu->cbf[comp][part] >> (trIdx - 1)) & 1)) {
+            const int lowest = trIdx + ((subdiv && !(tu.cwo >= 8)) ? 1 : 0);
+            cab_bin(c, (cu->cbf[comp][cuPart + tu_part_c(tu)] >> lowest) & 1, CTX_CBF_CHROMA + trIdx);
+          }
+      if (!subdiv) {
+        cab_bin(c, (cu->cbf[0][part] >> trIdx) & 1, CTX_CBF_LUMA + (trIdx == 0 ? 1 : 0));
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && tu.cw == 0) continue;
+          if (!((cu->cbf[comp][part] >> trIdx) & 1)) continue;
+          const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
+          const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
+          const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
+          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p);
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 1); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+FCU_DEV void encode_cu_syntax(const Env &E, Cabac *c, const CuObj *cu, int cuPart, int depth)   /* TEncCu.cpp:2117-2141 / 1753-1778 */
+{
+  if (depth == MAXDEPTH) cab_bin(c, cu->part_size[cuPart] == SIZE_2Nx2N, CTX_PARTSIZE);
+  code_intra_dir_luma(E, c, cu, cuPart, 1);
+  code_intra_dir_chroma(c, cu->intra_dir[1][cuPart]);
+  TU root; tu_root(root, depth);
+  encode_transform(E, c, cu, cuPart, root);
+}
+
+/* ======================================================================================== */
+/* CU object helpers (cooperative)                                                           */
+/* ======================================================================================== */
+FCU_DEV void cu_init(const Env &E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
+{
+  const int n = NPART >> (2 * depth), s = CTU >> depth;
+  FCU_FOR_LANES {
+    if (lane == 0) { cu->cost = FCU_MAX_DOUBLE; cu->dist = 0; cu->bits = 0; cu->bins = 0; cu->depth_cu = depth; cu->x = x; cu->y = y; cu->zidx = zidx; cu->nparts = n; }
+    for (int i = lane; i < n; i += 64) {
+      cu->depth[i] = (uint8_t)depth; cu->part_size[i] = SIZE_NONE; cu->pred_mode[i] = MODE_NONE; cu->tr_idx[i] = 0;
+      cu->tskip[0][i] = cu->tskip[1][i] = cu->tskip[2][i] = 0; cu->cbf[0][i] = cu->cbf[1][i] = cu->cbf[2][i] = 0;
+      cu->intra_dir[0][i] = DC; cu->intra_dir[1][i] = 0;
+    }
+    for (int i = lane; i < s * s; i += 64) cu->coef[0][i] = 0;
+    for (int i = lane; i < s * s / 4; i += 64) { cu->coef[1][i] = 0; cu->coef[2][i] = 0; }
+  }
+  (void)E;
+}
+FCU_DEV void cu_copy_part_from(const Env &E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
+{
+  const int n = src->nparts, off = partUnitIdx * n;
+  FCU_FOR_LANES {
+    if (lane == 0) { dst->dist += src->dist; dst->bits += src->bits; dst->bins += src->bins; }
+    for (int i = lane; i < n; i += 64) {
+      dst->depth[off + i] = src->depth[i]; dst->part_size[off + i] = src->part_size[i]; dst->pred_mode[off + i] = src->pred_mode[i];
+      dst->tr_idx[off + i] = src->tr_idx[i];
+      for (int c = 0; c < 3; c++) { dst->tskip[c][off + i] = src->tskip[c][i]; dst->cbf[c][off + i] = src->cbf[c][i]; }
+      dst->intra_dir[0][off + i] = src->intra_dir[0][i]; dst->intra_dir[1][off + i] = src->intra_dir[1][i];
+    }
+    for (int i = lane; i < n * 16; i += 64) dst->coef[0][off * 16 + i] = src->coef[0][i];
+    for (int i = lane; i < n * 4; i += 64) { dst->coef[1][off * 4 + i] = src->coef[1][i]; dst->coef[2][off * 4 + i] = src->coef[2][i]; }
+  }
+  (void)E;
+}
+FCU_DEV void cu_copy_to_pic(const Env &E, const CuObj *cu)                             /* copyToPic */
+{
+  fcu_ctu_out *p = &E.C->out[E.cur_ctu];
+  const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
+  FCU_FOR_LANES {
+    if (lane == 0) { p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins; }
+    for (int i = lane; i < n; i += 64) {
+      p->depth[off + i] = cu->depth[i]; p->width[off + i] = (uint8_t)s; p->height[off + i] = (uint8_t)s; p->skip[off + i] = 0;
+      p->part_size[off + i] = cu->part_size[i]; p->pred_mode[off + i] = cu->pred_mode[i]; p->qp[off + i] = (int8_t)qp;
+      p->tr_idx[off + i] = cu->tr_idx[i];
+      for (int c = 0; c < 3; c++) { p->tskip[c][off + i] = cu->tskip[c][i]; p->cbf[c][off + i] = cu->cbf[c][i]; }
+      p->intra_dir[0][off + i] = cu->intra_dir[0][i]; p->intra_dir[1][off + i] = cu->intra_dir[1][i];
+    }
+    for (int i = lane; i < n * 16; i += 64) p->coeff_y[off * 16 + i] = cu->coef[0][i];
+    for (int i = lane; i < n * 4; i += 64) { p->coeff_cb[off * 4 + i] = cu->coef[1][i]; p->coeff_cr[off * 4 + i] = cu->coef[2][i]; }
+  }
+}
+FCU_DEV void copy_reco_to_pic(const Env &E, const Yuv *r, int x, int y, int s)
+{
+  FCU_FOR_LANES {
+    for (int c = 0; c < 3; c++) {
+      const int sh = c ? 1 : 0, bs = c ? 32 : 64, w = E.C->p.width >> sh, h = E.C->p.height >> sh;
+      const uint8_t *src = c == 0 ? r->y : (c == 1 ? r->u : r->v);
+      const int px = x >> sh, py = y >> sh, n = s >> sh;
+      for (int i = lane; i < n * n; i += 64) { const int yy = i / n, xx = i % n; if (py + yy < h && px + xx < w) E.C->rec[c][(py + yy) * E.C->stride[c] + px + xx] = src[yy * bs + xx]; }
+    }
+  }
+}
+
+/* ======================================================================================== */
+/* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
+/* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
+/* ======================================================================================== */
+FCU_DEV void tu_trial(const Env &E, CuObj *cu, const TU &tu, int comp, Cabac *cab, int save1load2)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  if (comp && tu.cw == 0) { FCU_SERIAL { S->t_dist = 0; S->t_abs = 0; } return; }
+  const int d = cu->depth_cu, N = comp ? tu.cw : (1 << tu.log2), log2 = ilog2(N), n2 = N * N;
+  const int bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y, bs = comp ? 32 : 64, sh = comp ? 1 : 0;
+  const int part = tu.part, layer = LOG2_MAXTU - tu.log2;
+  uint8_t *org = yuv_plane(&G->org[d], comp) + by * bs + bx;
+  uint8_t *pred = yuv_plane(&G->predt[d], comp) + by * bs + bx;
+  uint8_t *recqt = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx;
+  const int px = (cu->x >> sh) + bx, py = (cu->y >> sh) + by;
+  uint8_t *recpic = E.C->rec[comp] + py * E.C->stride[comp] + px; const int rs = E.C->stride[comp];
+  int16_t *coef = G->qt_coef[comp][layer] + (comp ? tu.off_c : tu.off_y);
+  const int useTS = cu->tskip[comp][part];
+  const int mode = comp ? chroma_final_mode(cu, part) : cu->intra_dir[0][part];
+  const int useDst = comp == 0 && log2 == 2;
+  const int qp = comp ? P.qp_c : P.qp;
+
+  if (save1load2 != 2) {
+    const int filt = use_filtered_ref(mode, log2, comp == 0);
+    build_ref(E, comp, px, py, log2, filt);
+    FCU_FOR_LANES {
+      const uint8_t *r = filt ? S->reff : S->ref; const int dc = S->dc;
+      for (int i = lane; i < n2; i += 64) {
+        const int y = i >> log2, x = i & (N - 1);
+        const int v = pred_pixel(r, log2, mode, comp == 0, dc, x, y);
+        pred[y * bs + x] = (uint8_t)v;
+        if (save1load2 == 1) G->shared_pred[comp][i] = (uint8_t)v;
+        G->p_resi[i] = (int16_t)(org[y * bs + x] - v);
+      }
+    }
+  } else {
+    FCU_FOR_LANES {
+      for (int i = lane; i < n2; i += 64) {
+        const int y = i >> log2, x = i & (N - 1); const int v = G->shared_pred[comp][i];
+        pred[y * bs + x] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * bs + x] - v);
+      }
+    }
+  }
+  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = (int32_t)G->p_resi[i] << (15 - 8 - log2); } }
+  else {
+    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1(G->p_resi, log2, useDst, i); }
+    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = fwd2(G->p_tmp, log2, useDst, i); }
+  }
+  FCU_FOR_LANES {
+    if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
+    if (lane == 0) {
+      RdoqBuf rb = { G->r_cc, G->r_cs, G->r_c0, G->r_up, G->r_dn, G->r_sd, G->r_du };
+      const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+      S->t_abs = rdoq(cab, G->p_tcoef, G->p_qcoef, log2, comp, coef_scan_idx(mode, log2, comp), cbfCtx, P, rb);
+      E.C->n_tu_trials++;
+    }
+  }
+  const int absSum = S->t_abs;
+  FCU_FOR_LANES {                                            /* setCbfPartRange + coefficient store */
+    const int np = comp ? tu_nparts_c(tu) : tu.nparts;
+    for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
+    for (int i = lane; i < n2; i += 64) { const int q = absSum > 0 ? G->p_qcoef[i] : 0; coef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
+  }
+  if (absSum > 0) {
+    if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
+    else {
+      FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = inv1(G->p_tmp, log2, useDst, i); }
+      FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)inv2(G->p_tcoef, log2, useDst, i); }
+    }
+  }
+  FCU_FOR_LANES {
+    if (lane == 0) S->sad[35] = 0;
+  }
+  FCU_FOR_LANES {
+    uint32_t sse = 0;
+    for (int i = lane; i < n2; i += 64) {
+      const int y = i >> log2, x = i & (N - 1);
+      const int r = clip8(pred[y * bs + x] + (absSum > 0 ? G->p_resi[i] : 0));
+      pred[y * bs + x] = (uint8_t)r; recqt[y * bs + x] = (uint8_t)r; recpic[y * rs + x] = (uint8_t)r;
+      const int e = org[y * bs + x] - r; sse += (uint32_t)(e * e);
+    }
+    FCU_ATOMIC_ADD(&S->sad[35], sse);
+  }
+  FCU_SERIAL { const uint32_t sse = S->sad[35]; S->t_dist = comp ? (uint32_t)(P.chroma_weight * (double)sse) : sse; }
+}
+
+/* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
+FCU_DEV void store_intra_result_qt(const Env &E, const TU &tu, int comp)
+{
+  Scratch *G = E.G;
+  if (comp && tu.cw == 0) return;
+  const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
+  const int16_t *src = G->qt_coef[comp][layer] + (comp ? tu.off_c : tu.off_y);
+  const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
+  FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
+}
+FCU_DEV void load_intra_result_qt(const Env &E, const CuObj *cu, const TU &tu, int comp)
+{
+  Scratch *G = E.G;
+  if (comp && tu.cw == 0) return;
+  const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, sh = comp ? 1 : 0, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
+  int16_t *dst = G->qt_coef[comp][layer] + (comp ? tu.off_c : tu.off_y);
+  uint8_t *t = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; const uint8_t *s = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
+  uint8_t *pic = E.C->rec[comp] + ((cu->y >> sh) + by) * E.C->stride[comp] + (cu->x >> sh) + bx; const int rs = E.C->stride[comp];
+  FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { dst[i] = G->ts_coef[comp][i]; const uint8_t v = s[(i / N) * bs + (i % N)]; t[(i / N) * bs + (i % N)] = v; pic[(i / N) * rs + (i % N)] = v; } }
+}
+
+/* ======================================================================================== */
+/* xRecurIntraCodingLumaQT (sequential path), TEncSearch.cpp:1393-1713                        */
+/* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to S->q_dist/q_cost[LEVEL].   */
+/* ======================================================================================== */
+template <int LEVEL>
+FCU_DEV void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
+  const int partSize = cu->part_size[part];
+  const int checkFull = log2 <= LOG2_MAXTU;
+  int checkSplit = log2 > min_tu_log2_in_cu(d, partSize);
+  if (checkFirst && checkFull) checkSplit = 0;
+  int checkTS = P.transform_skip && log2 == 2;
+  if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
+  double singleCost = FCU_MAX_DOUBLE; uint32_t singleDist = 0, singleCbf = 0; int bestModeId = 0;
+
+  if (checkFull) {
+    if (checkTS) {
+      FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      for (int modeId = 0; modeId < 2; modeId++) {
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)modeId; }
+        tu_trial(E, cu, tu, 0, &S->goon, modeId == 0 ? 1 : 2);
+        const uint32_t tmpDist = S->t_dist, tmpCbf = (cu->cbf[0][part] >> trDepth) & 1;
+        double tmpCost;
+        if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
+        else {
+          FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
+          tmpCost = rd_cost(P, S->vc_bits[0], tmpDist);
+        }
+        if (tmpCost < singleCost) {
+          singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
+          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_TEMP_BEST], &S->goon, lane); }
+        }
+        if (modeId == 0) FCU_FOR_LANES cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
+      }
+      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)bestModeId; }
+      if (bestModeId == 0) {
+        load_intra_result_qt(E, cu, tu, 0);
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&S->goon, &S->slot[fullDepth][CI_TEMP_BEST], lane); }
+      }
+    } else {
+      if (checkSplit) FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = 0; }
+      tu_trial(E, cu, tu, 0, &S->goon, 0);
+      singleDist = S->t_dist;
+      if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
+      FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
+      singleCost = rd_cost(P, S->vc_bits[0], singleDist);
+    }
+  }
+  if (checkSplit) {
+    if constexpr (LEVEL < 3) {
+      if (checkFull) { FCU_FOR_LANES { cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_TEST], &S->goon, lane); } FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane); } }
+      else FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      FCU_SERIAL { S->q_dist[LEVEL + 1] = 0; S->q_cost[LEVEL + 1] = 0; }
+      uint32_t splitCbf = 0;
+      for (int i = 0; i < 4; i++) {
+        TU c; tu_child(c, tu, i, 0);
+        recur_luma_qt<LEVEL + 1>(E, cu, c, checkFirst);
+        splitCbf |= (cu->cbf[0][c.part] >> c.tr_depth) & 1;
+      }
+      const uint32_t splitDist = S->q_dist[LEVEL + 1];
+      FCU_FOR_LANES {
+        if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
+        cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
+      }
+      FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
+      const double splitCost = rd_cost(P, S->vc_bits[0], splitDist);
+      if (splitCost < singleCost) { FCU_SERIAL { S->q_dist[LEVEL] += splitDist; S->q_cost[LEVEL] += splitCost; } return; }
+      FCU_FOR_LANES {
+        cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_TEST], lane);
+        for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cu->tskip[0][part + i] = (uint8_t)bestModeId; }
+        const int N = 1 << log2, layer = LOG2_MAXTU - log2;
+        const uint8_t *s = G->qt_rec[layer].y + tu.y * 64 + tu.x;
+        uint8_t *p = E.C->rec[0] + (cu->y + tu.y) * E.C->stride[0] + cu->x + tu.x; const int rs = E.C->stride[0];
+        for (int i = lane; i < N * N; i += 64) p[(i >> log2) * rs + (i & (N - 1))] = s[(i >> log2) * 64 + (i & (N - 1))];
+      }
+    }
+  }
+  FCU_SERIAL { S->q_dist[LEVEL] += singleDist; S->q_cost[LEVEL] += singleCost; }
+}
+
+/* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
+FCU_DEV void set_intra_result_luma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)
+{
+  Scratch *G = E.G;
+  TU st[4]; int ci[4]; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU tu = st[sp];
+    if (ci[sp] < 0) {
+      if (cu->tr_idx[tu.part] == tu.tr_depth) {
+        const int N = 1 << tu.log2, layer = LOG2_MAXTU - tu.log2;
+        FCU_FOR_LANES {
+          for (int i = lane; i < N * N; i += 64) {
+            cu->coef[0][tu.off_y + i] = G->qt_coef[0][layer][tu.off_y + i];
+            const int yy = tu.y + (i >> tu.log2), xx = tu.x + (i & (N - 1));
+            reco->y[yy * 64 + xx] = G->qt_rec[layer].y[yy * 64 + xx];
+          }
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+
+/* ======================================================================================== */
+/* RMD: 35 predictions + Hadamard SATD staged through LDS (TEncSearch.cpp:2300-2361,          */
+/* TComRdCost.cpp:1343-1604) and the sorted candidate list (xUpdateCandList :5345-5370)       */
+/* ======================================================================================== */
+FCU_DEV void rmd(const Env &E, CuObj *cu, const TU &tu)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
+  build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
+  const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
+  const int usz = N >= 8 ? 8 : 4, ul = usz == 8 ? 3 : 2, upix = usz * usz, bpr = N / usz, nblk = bpr * bpr;
+  const int totalUnits = 35 * nblk, K = DIFFN / upix;
+  FCU_FOR_LANES { if (lane < 36) S->sad[lane] = 0; }
+  for (int u0 = 0; u0 < totalUnits; u0 += K) {
+    const int nu = (totalUnits - u0) < K ? (totalUnits - u0) : K;
+    FCU_FOR_LANES {                                          /* residual of unit u = (mode, block) */
+      const int dc = S->dc;
+      for (int i = lane; i < nu * upix; i += 64) {
+        const int u = u0 + (i >> (2 * ul)), p = i & (upix - 1), mode = u / nblk, blk = u % nblk;
+        const int x = (blk % bpr) * usz + (p & (usz - 1)), y = (blk / bpr) * usz + (p >> ul);
+        const uint8_t *r = use_filtered_ref(mode, log2, 1) ? S->reff : S->ref;
+        S->diff[i] = (int16_t)(org[y * 64 + x] - pred_pixel(r, log2, mode, 1, dc, x, y));
+      }
+    }
+    FCU_FOR_LANES {                                          /* rows */
+      for (int it = lane; it < nu * usz; it += 64) {
+        int16_t *row = S->diff + it * usz; int v[8];
+        for (int k = 0; k < usz; k++) v[k] = row[k];
+        for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+        for (int k = 0; k < usz; k++) row[k] = (int16_t)v[k];
+      }
+    }
+    FCU_FOR_LANES {                                          /* columns + abs sum */
+      for (int it = lane; it < nu * usz; it += 64) {
+        const int16_t *col = S->diff + (it >> ul) * upix + (it & (usz - 1)); int v[8];
+        for (int k = 0; k < usz; k++) v[k] = col[k * usz];
+        for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+        int s = 0; for (int k = 0; k < usz; k++) s += iabs(v[k]);
+        S->colsum[it] = s;
+      }
+    }
+    FCU_FOR_LANES {
+      for (int uu = lane; uu < nu; uu += 64) {
+        int s = 0; for (int k = 0; k < usz; k++) s += S->colsum[uu * usz + k];
+        const uint32_t v = (uint32_t)(usz == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
+        FCU_ATOMIC_ADD(&S->sad[(u0 + uu) / nblk], v);
+      }
+    }
+  }
+  /* mode bits + sorted insert (serial) */
+  FCU_SERIAL {
+    int preds[3];
+    const int nm = intra_dir_predictor(E, cu, tu.part, preds);
+    S->preds[0] = preds[0]; S->preds[1] = preds[1]; S->preds[2] = preds[2]; S->n_mpm = nm;
+    const Cabac *cb = &S->slot[d][CI_CURR_BEST];
+    const uint64_t carry = cb->frac & 32767;               /* loadIntraDirMode + resetBits, TEncSearch.cpp:5313-5340 */
+    int numFull = k_rd_mode_num[log2 - 2];
+    double candCost[12];
+    for (int i = 0; i < numFull; i++) candCost[i] = FCU_MAX_DOUBLE;
+    for (int mode = 0; mode < 35; mode++) {
+      int predIdx = -1;
+      for (int i = 0; i < 3; i++) if (mode == preds[i]) predIdx = i;
+      const uint64_t fr = carry + (uint64_t)ctx_bits(cb, CTX_INTRA_LUMA, predIdx != -1) + (uint64_t)32768 * (uint64_t)(predIdx != -1 ? (predIdx ? 2 : 1) : 5);
+      const uint32_t modeBits = (uint32_t)(fr >> 15);
+      const double cost = (double)S->sad[mode] + (double)modeBits * P.sqrt_lambda;
+      int shift = 0;
+      while (shift < numFull && cost < candCost[numFull - 1 - shift]) shift++;
+      if (shift != 0) {
+        for (int i = 1; i < shift; i++) { S->rd_mode[numFull - i] = S->rd_mode[numFull - 1 - i]; candCost[numFull - i] = candCost[numFull - 1 - i]; }
+        S->rd_mode[numFull - shift] = mode; candCost[numFull - shift] = cost;
+      }
+    }
+    for (int j = 0; j < nm; j++) {
+      int inc = 0;
+      for (int i = 0; i < numFull; i++) inc |= (preds[j] == S->rd_mode[i]);
+      if (!inc) S->rd_mode[numFull++] = preds[j];
+    }
+    S->n_rd = numFull;
+  }
+}
+
+/* ======================================================================================== */
+/* first-pass RDO of one PU whose TU is not split: all candidates (x transform-skip variants) */
+/* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
+/* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
+/* ======================================================================================== */
+FCU_DEV void pu_first_pass_batched(const Env &E, CuObj *cu, const TU &tu)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
+  const int partSize = cu->part_size[part];
+  int checkTS = P.transform_skip && log2 == 2;
+  if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
+  const int nc = S->n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
+  const int useDst = log2 == 2;
+  const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
+  /* reference samples are shared by all candidates: the TU is the whole PU */
+  build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
+  FCU_FOR_LANES {                                            /* prediction + residual per candidate */
+    const int dc = S->dc;
+    for (int i = lane; i < nc * n2; i += 64) {
+      const int cnd = i / n2, p = i - cnd * n2, y = p >> log2, x = p & (N - 1), mode = S->rd_mode[cnd];
+      const uint8_t *r = use_filtered_ref(mode, log2, 1) ? S->reff : S->ref;
+      const int v = pred_pixel(r, log2, mode, 1, dc, x, y);
+      G->p_pred[i] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * 64 + x] - v);
+    }
+  }
+  FCU_FOR_LANES { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1(G->p_resi + cnd * n2, log2, useDst, i - cnd * n2); } }
+  FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
+    for (int i = lane; i < nvc * n2; i += 64) {
+      const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
+      G->p_tcoef[i] = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
+    }
+  }
+  FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
+    if (lane < nvc) {
+      const int mode = S->rd_mode[lane / tsv];
+      RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2 };
+      const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
+      S->vc_abs[lane] = rdoq(&S->slot[d][CI_CURR_BEST], G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
+      S->vc_dist[lane] = 0;
+    }
+    if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
+  }
+  FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = S->vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp) : 0; } }
+  FCU_FOR_LANES {
+    for (int i = lane; i < nvc * n2; i += 64) {
+      const int v = i / n2, p = i - v * n2, ts = v % tsv;
+      if (ts) { const int s = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (s - 1))) >> s; }
+      else G->p_tcoef[i] = inv1(G->p_tmp + v * n2, log2, useDst, p);
+    }
+  }
+  FCU_FOR_LANES {
+    for (int i = lane; i < nvc * n2; i += 64) {
+      const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+      int res = 0;
+      if (S->vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, useDst, p);
+      const int r = clip8(G->p_pred[cnd * n2 + p] + res);
+      G->p_rec[i] = (uint8_t)r;
+      const int e = org[y * 64 + x] - r;
+      FCU_ATOMIC_ADD(&S->vc_dist[v], (uint32_t)(e * e));
+    }
+  }
+  FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
+    if (lane < nvc) {
+      const int cnd = lane / tsv, ts = lane % tsv, mode = S->rd_mode[cnd], cbf = S->vc_abs[lane] > 0;
+      double cost;
+      if (ts && !cbf) cost = FCU_MAX_DOUBLE;                 /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
+      else {
+        Cabac *c = &S->lane[lane];
+        cab_copy1(c, &S->slot[d][CI_CURR_BEST]);
+        cab_reset_bits(c);
+        if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
+        code_luma_dir_bits(c, mode, S->preds);
+        if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
+          cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
+        cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P);
+        S->vc_bits[lane] = cab_bits(c);
+        cost = rd_cost(P, S->vc_bits[lane], S->vc_dist[lane]);
+      }
+      S->vc_cost[lane] = cost;
+    }
+  }
+  FCU_SERIAL {                                               /* strict '<', earlier candidate wins ties */
+    double best = FCU_MAX_DOUBLE; int bv = 0;
+    for (int cnd = 0; cnd < nc; cnd++) {
+      int v = cnd * tsv; double c = S->vc_cost[v];
+      if (tsv == 2 && S->vc_cost[v + 1] < c) { v = v + 1; c = S->vc_cost[v]; }
+      if (c < best) { best = c; bv = v; }
+    }
+    S->pu_best_vc = bv; S->pu_best_cost = best; S->pu_best_dist = S->vc_dist[bv]; S->pu_best_mode = S->rd_mode[bv / tsv];
+  }
+  {                                                          /* xSetIntraResultLumaQT + decision snapshot */
+    const int bv = S->pu_best_vc, ts = bv % tsv, cbf = S->vc_abs[bv] > 0;
+    Yuv *reco = &G->reco[d][1 - S->reco_best_idx[d]];
+    FCU_FOR_LANES {
+      for (int i = lane; i < n2; i += 64) {
+        cu->coef[0][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
+        reco->y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
+      }
+      for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = (uint8_t)tu.tr_depth; G->tmp_cbf[i] = (uint8_t)(cbf << tu.tr_depth); G->tmp_tskip[i] = (uint8_t)ts; }
+    }
+  }
+}
+
+/* ======================================================================================== */
+/* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
+/* ======================================================================================== */
+FCU_DEV void est_intra_pred_luma(const Env &E, CuObj *cu)
+{
+  Shared *S = E.S; Scratch *G = E.G;
+  const int d = cu->depth_cu, partSize = cu->part_size[0];
+  const int initTrDepth = partSize == SIZE_2Nx2N ? 0 : 1, numPU = 1 << (2 * initTrDepth), qNumParts = cu->nparts >> 2;
+  uint32_t overallDistY = 0;
+  TU root; tu_root(root, d);
+  Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+  for (int pu = 0; pu < numPU; pu++) {
+    TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
+    const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
+    rmd(E, cu, tu);
+    const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
+    if (singleTU) pu_first_pass_batched(E, cu, tu);
+    else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
+      FCU_SERIAL { S->pu_best_cost = FCU_MAX_DOUBLE; S->pu_best_mode = 0; S->pu_best_dist = 0; }
+      const int nc = S->n_rd;
+      for (int m = 0; m < nc; m++) {
+        const int orgMode = S->rd_mode[m];
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
+        recur_luma_qt<0>(E, cu, tu, 1);
+        if (S->q_cost[0] < S->pu_best_cost) {
+          FCU_SERIAL { S->pu_best_mode = orgMode; S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
+          set_intra_result_luma_qt(E, cu, tu, recoT);
+          FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
+        }
+      }
+    }
+    /* best mode again with the full RQT (TEncSearch.cpp:2518-2586).  When the TU cannot split the
+     * re-run reproduces the first-pass trial exactly (same snapshot, same inputs) and `<` keeps the
+     * earlier result, so it is skipped. */
+    if (log2 > min_tu_log2_in_cu(d, partSize)) {
+      const int orgMode = S->pu_best_mode;
+      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
+      recur_luma_qt<0>(E, cu, tu, 0);
+      if (S->q_cost[0] < S->pu_best_cost) {
+        FCU_SERIAL { S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
+        set_intra_result_luma_qt(E, cu, tu, recoT);
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
+      }
+    }
+    overallDistY += S->pu_best_dist;
+    const int bestMode = S->pu_best_mode;
+    FCU_FOR_LANES {
+      for (int i = lane; i < tu.nparts; i += 64) {
+        cu->tr_idx[partOffset + i] = G->tmp_tr_idx[i]; cu->cbf[0][partOffset + i] = G->tmp_cbf[i]; cu->tskip[0][partOffset + i] = G->tmp_tskip[i];
+        cu->intra_dir[0][partOffset + i] = (uint8_t)bestMode;
+      }
+      if (pu != numPU - 1) {
+        uint8_t *p = E.C->rec[0] + (cu->y + tu.y) * E.C->stride[0] + cu->x + tu.x; const int rs = E.C->stride[0];
+        for (int i = lane; i < N * N; i += 64) p[(i >> log2) * rs + (i & (N - 1))] = recoT->y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))];
+      }
+    }
+  }
+  if (numPU > 1) {
+    FCU_SERIAL {
+      uint8_t cy = 0, cu1 = 0, cv = 0;
+      for (int p = 0, idx = 0; p < 4; p++, idx += qNumParts) { cy |= (cu->cbf[0][idx] >> 1) & 1; cu1 |= (cu->cbf[1][idx] >> 1) & 1; cv |= (cu->cbf[2][idx] >> 1) & 1; }
+      for (int o = 0; o < 4 * qNumParts; o++) { cu->cbf[0][o] |= cy; cu->cbf[1][o] |= cu1; cu->cbf[2][o] |= cv; }
+    }
+  }
+  FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) cu->dist = overallDistY; }
+}
+
+/* ======================================================================================== */
+/* chroma: xRecurIntraChromaCodingQT / estIntraPredChromaQT, TEncSearch.cpp:1916-2120,2661-2810 */
+/* ======================================================================================== */
+template <int LEVEL>
+FCU_DEV void recur_chroma_qt(const Env &E, CuObj *cu, const TU &tu)
+{
+  Shared *S = E.S; const Params &P = E.C->p;
+  const int part = tu.part, trDepth = tu.tr_depth;
+  if (cu->tr_idx[part] == trDepth) {
+    if (tu.cw == 0) return;
+    const int fullDepth = cu->depth_cu + trDepth;
+    int checkTS = P.transform_skip && tu.cw <= 4;
+    if (P.ts_fast) {
+      checkTS = checkTS && (tu.log2 == 2);
+      if (checkTS) { int nb = 0; const int maxp = part + (tu.c_code_all ? 1 : 4); for (int p = part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
+    }
+    const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
+    for (int comp = 1; comp < 3; comp++) {
+      FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      double singleCost = FCU_MAX_DOUBLE, tmpCost = 0; int bestModeId = 0, bestTS = 0; uint32_t singleDistC = 0, singleCbfC = 0;
+      const int modesToTest = checkTS ? 2 : 1;
+      int currModeId = 0;
+      for (int tsMode = 0; tsMode < modesToTest; tsMode++) {
+        FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->tskip[comp][subPart + i] = (uint8_t)tsMode; }
+        currModeId++;
+        const int isOne = modesToTest == 1, isLast = currModeId == modesToTest;
+        tu_trial(E, cu, tu, comp, &S->goon, isOne ? 0 : (tsMode == 0 ? 1 : 2));
+        const uint32_t tmpDist = S->t_dist, tmpCbf = (cu->cbf[comp][subPart] >> trDepth) & 1;
+        if (tsMode == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
+        else if (!isOne) {
+          FCU_SERIAL { cab_reset_bits(&S->goon); enc_coeff_qt(E, &S->goon, cu, tu, comp, 0); S->vc_bits[0] = cab_bits(&S->goon); }
+          tmpCost = rd_cost(P, S->vc_bits[0], tmpDist);
+        }
+        if (tmpCost < singleCost) {
+          singleCost = tmpCost; singleDistC = tmpDist; bestTS = tsMode; bestModeId = currModeId; singleCbfC = tmpCbf;
+          if (!isOne && !isLast) { store_intra_result_qt(E, tu, comp); FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_TEMP_BEST], &S->goon, lane); }
+        }
+        if (!isOne && !isLast) FCU_FOR_LANES cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
+      }
+      if (bestModeId < modesToTest) {
+        load_intra_result_qt(E, cu, tu, comp);
+        FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->cbf[comp][subPart + i] = (uint8_t)(singleCbfC << trDepth); cab_copy(&S->goon, &S->slot[fullDepth][CI_TEMP_BEST], lane); }
+      }
+      FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->tskip[comp][subPart + i] = (uint8_t)bestTS; if (lane == 0) S->c_dist += singleDistC; }
+    }
+  } else {
+    if constexpr (LEVEL < 3) {
+      uint32_t splitCbf[3] = { 0, 0, 0 };
+      for (int i = 0; i < 4; i++) {
+        TU c; tu_child(c, tu, i, 0);
+        recur_chroma_qt<LEVEL + 1>(E, cu, c);
+        for (int comp = 1; comp < 3; comp++) splitCbf[comp] |= (cu->cbf[comp][c.part] >> c.tr_depth) & 1;
+      }
+      FCU_FOR_LANES { for (int comp = 1; comp < 3; comp++) if (splitCbf[comp]) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[comp][part + o] |= (uint8_t)(1 << trDepth); }
+    }
+  }
+}
+FCU_DEV void set_intra_result_chroma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)   /* TEncSearch.cpp:2126-2175 */
+{
+  Scratch *G = E.G;
+  TU st[4]; int ci[4]; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU tu = st[sp];
+    if (ci[sp] < 0) {
+      if (tu.cw == 0) { sp--; continue; }
+      if (cu->tr_idx[tu.part] == tu.tr_depth) {
+        const int N = tu.cw, layer = LOG2_MAXTU - tu.log2;
+        FCU_FOR_LANES {
+          for (int i = lane; i < N * N; i += 64) {
+            const int yy = tu.cy + i / N, xx = tu.cx + i % N;
+            cu->coef[1][tu.off_c + i] = G->qt_coef[1][layer][tu.off_c + i]; cu->coef[2][tu.off_c + i] = G->qt_coef[2][layer][tu.off_c + i];
+            reco->u[yy * 32 + xx] = G->qt_rec[layer].u[yy * 32 + xx]; reco->v[yy * 32 + xx] = G->qt_rec[layer].v[yy * 32 + xx];
+          }
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+FCU_DEV void est_intra_pred_chroma(const Env &E, CuObj *cu)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, n = cu->nparts;
+  TU tu; tu_root(tu, d);
+  Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+  FCU_SERIAL { S->c_best_cost = FCU_MAX_DOUBLE; S->c_best_mode = 0; S->c_best_dist = 0; }
+  int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
+  { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
+  for (int m = 0; m < 5; m++) {
+    const int mode = modeList[m];
+    FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); for (int i = lane; i < n; i += 64) cu->intra_dir[1][i] = (uint8_t)mode; if (lane == 0) S->c_dist = 0; }
+    recur_chroma_qt<0>(E, cu, tu);
+    FCU_FOR_LANES { if (P.transform_skip) cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); }
+    FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 0, 1); }
+    const uint32_t dist = S->c_dist;
+    const double cost = rd_cost(P, S->vc_bits[0], dist);
+    if (cost < S->c_best_cost) {
+      FCU_SERIAL { S->c_best_cost = cost; S->c_best_dist = dist; S->c_best_mode = mode; }
+      set_intra_result_chroma_qt(E, cu, tu, recoT);
+      FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { G->tmpc_cbf[0][i] = cu->cbf[1][i]; G->tmpc_cbf[1][i] = cu->cbf[2][i]; G->tmpc_tskip[0][i] = cu->tskip[1][i]; G->tmpc_tskip[1][i] = cu->tskip[2][i]; } }
+    }
+  }
+  const int bm = S->c_best_mode; const uint32_t bd = S->c_best_dist;
+  FCU_FOR_LANES {
+    for (int i = lane; i < n; i += 64) { cu->cbf[1][i] = G->tmpc_cbf[0][i]; cu->cbf[2][i] = G->tmpc_cbf[1][i]; cu->tskip[1][i] = G->tmpc_tskip[0][i]; cu->tskip[2][i] = G->tmpc_tskip[1][i]; cu->intra_dir[1][i] = (uint8_t)bm; }
+    if (lane == 0) cu->dist += bd;
+    cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane);
+  }
+}
+
+/* ======================================================================================== */
+/* CU level: xCheckRDCostIntra / xCheckBestMode / xCompressCU (TEncCu.cpp:460-1616,2064-2255)  */
+/* ======================================================================================== */
+FCU_DEV CuObj *cu_best(const Env &E, int d) { return &E.G->cu[d][E.S->best_idx[d]]; }
+FCU_DEV CuObj *cu_temp(const Env &E, int d) { return &E.G->cu[d][1 - E.S->best_idx[d]]; }
+
+FCU_DEV void check_best_mode(const Env &E, int d)
+{
+  Shared *S = E.S;
+  const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
+  FCU_FOR_LANES {
+    if (change) { cab_copy(&S->slot[d][CI_NEXT_BEST], &S->slot[d][CI_TEMP_BEST], lane); if (lane == 0) { S->best_idx[d] = 1 - S->best_idx[d]; S->reco_best_idx[d] = 1 - S->reco_best_idx[d]; } }
+  }
+}
+FCU_DEV void check_rd_cost_intra(const Env &E, int d, int partSize)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  CuObj *cu = cu_temp(E, d);
+  const int n = cu->nparts, s = CTU >> d;
+  FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTRA; } }
+  est_intra_pred_luma(E, cu);
+  {
+    const Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+    FCU_FOR_LANES { uint8_t *p = E.C->rec[0] + cu->y * E.C->stride[0] + cu->x; const int rs = E.C->stride[0]; for (int i = lane; i < s * s; i += 64) p[(i / s) * rs + (i % s)] = recoT->y[(i / s) * 64 + (i % s)]; }
+  }
+  est_intra_pred_chroma(E, cu);
+  FCU_FOR_LANES {
+    if (lane == 0) {
+      cab_reset_bits(&S->goon);
+      encode_cu_syntax(E, &S->goon, cu, 0, d);
+      cu->bits = cab_bits(&S->goon); cu->bins = S->goon.bins;
+      cu->cost = rd_cost(P, cu->bits, cu->dist);
+    }
+  }
+  FCU_FOR_LANES cab_copy(&S->slot[d][CI_TEMP_BEST], &S->goon, lane);
+  check_best_mode(E, d);
+}
+
+template <int D>
+FCU_DEV void compress_cu(const Env &E)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const CuObj *b0 = cu_best(E, D);
+  const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
+  const int boundary = !((x + s - 1 < P.width) && (y + s - 1 < P.height));
+  if (!boundary) {
+    FCU_FOR_LANES {                                          /* source block -> L2-resident CU buffer */
+      for (int i = lane; i < s * s; i += 64) G->org[D].y[(i / s) * 64 + (i % s)] = E.C->org[0][(y + i / s) * E.C->stride[0] + x + (i % s)];
+      const int h = s / 2;
+      for (int i = lane; i < h * h; i += 64) {
+        G->org[D].u[(i / h) * 32 + (i % h)] = E.C->org[1][(y / 2 + i / h) * E.C->stride[1] + x / 2 + (i % h)];
+        G->org[D].v[(i / h) * 32 + (i % h)] = E.C->org[2][(y / 2 + i / h) * E.C->stride[2] + x / 2 + (i % h)];
+      }
+    }
+    cu_init(E, cu_temp(E, D), D, x, y, zidx);
+    check_rd_cost_intra(E, D, SIZE_2Nx2N);
+    cu_init(E, cu_temp(E, D), D, x, y, zidx);
+    if (D == MAXDEPTH) { check_rd_cost_intra(E, D, SIZE_NxN); cu_init(E, cu_temp(E, D), D, x, y, zidx); }
+    FCU_SERIAL {
+      CuObj *best = cu_best(E, D);
+      if (best->cost != FCU_MAX_DOUBLE) {                   /* fork: TEncCu.cpp:1224 */
+        cab_reset_bits(&S->goon);
+        code_split_flag(E, &S->goon, best, 0, D);
+        best->bits += cab_bits(&S->goon); best->bins += S->goon.bins;
+        best->cost = rd_cost(P, best->bits, best->dist);
+      }
+    }
+  }
+  cu_init(E, cu_temp(E, D), D, x, y, zidx);
+  if constexpr (D < MAXDEPTH) {
+    const int nd = D + 1, hs = s >> 1, qn = NPART >> (2 * nd);
+    for (int i = 0; i < 4; i++) {
+      const int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
+      cu_init(E, &G->cu[nd][0], nd, sx, sy, zidx + i * qn);
+      cu_init(E, &G->cu[nd][1], nd, sx, sy, zidx + i * qn);
+      if (sx < P.width && sy < P.height) {
+        FCU_FOR_LANES cab_copy(&S->slot[nd][CI_CURR_BEST], i == 0 ? &S->slot[D][CI_CURR_BEST] : &S->slot[nd][CI_NEXT_BEST], lane);
+        compress_cu<D + 1>(E);
+        cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
+        {                                                    /* xCopyYuv2Tmp */
+          const Yuv *src = &G->reco[nd][S->reco_best_idx[nd]]; Yuv *dst = &G->reco[D][1 - S->reco_best_idx[D]];
+          FCU_FOR_LANES {
+            for (int k = lane; k < hs * hs; k += 64) dst->y[((i >> 1) * hs + k / hs) * 64 + (i & 1) * hs + k % hs] = src->y[(k / hs) * 64 + k % hs];
+            const int h = hs / 2;
+            for (int k = lane; k < h * h; k += 64) { const int o = ((i >> 1) * h + k / h) * 32 + (i & 1) * h + k % h; dst->u[o] = src->u[(k / h) * 32 + k % h]; dst->v[o] = src->v[(k / h) * 32 + k % h]; }
+          }
+        }
+      } else {
+        cu_copy_to_pic(E, cu_best(E, nd));
+        cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
+      }
+    }
+    FCU_SERIAL {
+      CuObj *t = cu_temp(E, D);
+      if (!boundary) { cab_reset_bits(&S->goon); code_split_flag(E, &S->goon, t, 0, D); t->bits += cab_bits(&S->goon); t->bins += S->goon.bins; }
+      t->cost = rd_cost(P, t->bits, t->dist);
+    }
+    FCU_FOR_LANES cab_copy(&S->slot[D][CI_TEMP_BEST], &S->slot[nd][CI_NEXT_BEST], lane);
+    check_best_mode(E, D);
+  }
+  cu_copy_to_pic(E, cu_best(E, D));
+  copy_reco_to_pic(E, &G->reco[D][S->reco_best_idx[D]], x, y, s);
+}
+
+/* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */
+FCU_DEV void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, int lastCtuOfSlice)
+{
+  const Params &P = E.C->p;
+  int stPart[4], stChild[4]; int sp = 0;
+  stPart[0] = 0; stChild[0] = -1;
+  while (sp >= 0) {
+    const int depth = sp, part = stPart[sp];
+    if (stChild[sp] < 0) {
+      const int cx = ctu->x + part_x(part), cy = ctu->y + part_y(part), s = CTU >> depth;
+      int boundary = 0;
+      if (cx + s - 1 < P.width && cy + s - 1 < P.height) code_split_flag(E, c, ctu, part, depth); else boundary = 1;
+      if (!((depth < ctu->depth[part] && depth < MAXDEPTH) || boundary)) {
+        encode_cu_syntax(E, c, ctu, part, depth);
+        const int rx = cx + s, ry = cy + s;                  /* finishCU / isLastSubCUOfCtu, TEncCu.cpp:1629-1645 */
+        if (((rx % CTU) == 0 || rx == P.width) && ((ry % CTU) == 0 || ry == P.height) && !lastCtuOfSlice) cab_trm(c, 0);
+        sp--; continue;
+      }
+      stChild[sp] = 0;
+    }
+    if (stChild[sp] >= 4) { sp--; continue; }
+    {
+      const int qn = (NPART >> (2 * depth)) >> 2, p = part + stChild[sp] * qn;
+      stChild[sp]++;
+      if (ctu->x + part_x(p) < P.width && ctu->y + part_y(p) < P.height) { sp++; stPart[sp] = p; stChild[sp] = -1; }
+    }
+  }
+}
+
+/* ---- one CTU of one chain: the loop body of TEncSlice::compressSlice, TEncSlice.cpp:1380-1551 */
+FCU_DEV void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuRsAddr)
+{
+  Env E; E.C = C; E.G = G; E.S = S;
+  const Params &P = C->p;
+  const int sliceLen = P.slice_ctus > 0 ? P.slice_ctus : C->n_ctu;
+  const int sliceStart = (ctuRsAddr / sliceLen) * sliceLen;
+  int sliceEnd = sliceStart + sliceLen; if (sliceEnd > C->n_ctu) sliceEnd = C->n_ctu;
+  E.cur_ctu = ctuRsAddr; E.slice_start = sliceStart;
+  fcu_ctu_out *out = &C->out[ctuRsAddr];
+  const int x = (ctuRsAddr % C->w_ctu) * CTU, y = (ctuRsAddr / C->w_ctu) * CTU;
+  FCU_SERIAL { if (ctuRsAddr == sliceStart) cab_init(&S->slot[0][CI_CURR_BEST], P.qp); else cab_copy1(&S->slot[0][CI_CURR_BEST], &C->state); }
+  FCU_FOR_LANES {                                            /* TComDataCU::initCtu defaults, TComDataCU.cpp:474-560 */
+    for (int i = lane; i < NPART; i += 64) {
+      out->depth[i] = 0; out->width[i] = CTU; out->height[i] = CTU; out->skip[i] = 0; out->part_size[i] = SIZE_NONE; out->pred_mode[i] = MODE_NONE;
+      out->tq_bypass[i] = 0; out->qp[i] = (int8_t)P.qp; out->chroma_qp_adj[i] = 0; out->tr_idx[i] = 0; out->ipcm[i] = 0;
+      for (int c = 0; c < 3; c++) { out->tskip[c][i] = 0; out->cbf[c][i] = 0; }
+      out->intra_dir[0][i] = DC; out->intra_dir[1][i] = 0;
+    }
+    for (int i = lane; i < 4096; i += 64) out->coeff_y[i] = 0;
+    for (int i = lane; i < 1024; i += 64) { out->coeff_cb[i] = 0; out->coeff_cr[i] = 0; }
+    cab_copy(&S->goon, &S->slot[0][CI_CURR_BEST], lane);
+    if (lane == 0) { for (int d = 0; d < 4; d++) { S->best_idx[d] = 0; S->reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
+  }
+  cu_init(E, &G->cu[0][0], 0, x, y, 0);
+  cu_init(E, &G->cu[0][1], 0, x, y, 0);
+  compress_cu<0>(E);
+  /* encodeCtu on [0][CI_CURR_BEST] (TEncSlice.cpp:1474-1487): replay the winner to advance the contexts */
+  {
+    CuObj *view = cu_temp(E, 0);
+    FCU_FOR_LANES {
+      if (lane == 0) { view->depth_cu = 0; view->x = x; view->y = y; view->zidx = 0; view->nparts = NPART; }
+      for (int i = lane; i < NPART; i += 64) {
+        view->depth[i] = out->depth[i]; view->part_size[i] = out->part_size[i]; view->pred_mode[i] = out->pred_mode[i]; view->tr_idx[i] = out->tr_idx[i];
+        for (int c = 0; c < 3; c++) { view->tskip[c][i] = out->tskip[c][i]; view->cbf[c][i] = out->cbf[c][i]; }
+        view->intra_dir[0][i] = out->intra_dir[0][i]; view->intra_dir[1][i] = out->intra_dir[1][i];
+      }
+      for (int i = lane; i < 4096; i += 64) view->coef[0][i] = (int16_t)out->coeff_y[i];
+      for (int i = lane; i < 1024; i += 64) { view->coef[1][i] = (int16_t)out->coeff_cb[i]; view->coef[2][i] = (int16_t)out->coeff_cr[i]; }
+      cab_copy(&S->goon, &S->slot[0][CI_CURR_BEST], lane);
+    }
+    FCU_SERIAL {
+      cab_reset_bits(&S->goon);
+      encode_ctu(E, &S->goon, view, ctuRsAddr == sliceEnd - 1);
+      cab_copy1(&C->state, &S->goon);
+    }
+  }
+}
+
+} // namespace fcu

@@ -1,0 +1,58 @@
+/*
+ * fcu_host.h -- host-side derivation of the per-chain parameters that HM computes once per
+ * slice with libm (lambda, sqrt(lambda), chroma distortion weight, RDOQ lambdas, RDOQ error
+ * scales, sign-hiding rdFactor).  They are handed to the kernels as f64/i64 bit patterns so
+ * that no transcendental is ever evaluated on the device.
+ */
+#pragma once
+#include <math.h>
+#include "fcu_engine.h"
+
+namespace fcu {
+
+inline void fill_params(Params &p, int width, int height, const fcu_frame_params &fp)
+{
+  p.width = width; p.height = height; p.qp = fp.qp; p.slice_ctus = fp.slice_ctus;
+  p.transform_skip = fp.transform_skip; p.ts_fast = fp.transform_skip_fast;
+  p.sign_hiding = fp.sign_hiding; p.strong_smoothing = fp.strong_intra_smoothing;
+  /* chroma QP: g_aucChromaScale[CHROMA_420] (TLibCommon/TComRom.cpp:507), offsets 0 */
+  static const unsigned char chroma_scale[58] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+  p.qp_c = fp.qp < 0 ? fp.qp : chroma_scale[fp.qp > 57 ? 57 : fp.qp];
+  if (fp.lambda > 0.0) {
+    p.lambda = fp.lambda; p.sqrt_lambda = fp.sqrt_lambda; p.chroma_weight = fp.chroma_weight;
+    for (int i = 0; i < 3; i++) p.rdoq_lambda[i] = fp.rdoq_lambda[i];
+  } else {
+    /* TEncSlice::initEncSlice, I slice: lambda = 0.57 * 2^((QP-12)/3)  (TEncSlice.cpp:686-706) */
+    const double lambda = 0.57 * pow(2.0, ((double)fp.qp - 12) / 3.0);
+    const double w = pow(2.0, (fp.qp - p.qp_c) / 3.0);             /* setUpLambda, TEncSlice.cpp:496-524 */
+    p.lambda = lambda; p.sqrt_lambda = sqrt(lambda); p.chroma_weight = w;
+    p.rdoq_lambda[0] = lambda; p.rdoq_lambda[1] = lambda / w; p.rdoq_lambda[2] = lambda / w;
+  }
+  for (int ch = 0; ch < 2; ch++) {
+    const int qp = ch ? p.qp_c : p.qp, per = qp / 6, rem = qp % 6;
+    static const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };
+    static const int inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };
+    for (int l = 0; l < 4; l++) {
+      /* setErrScaleCoeff, TComTrQuant.cpp:3018-3040: 2^15 * 2^(-2*transformShift) / q / q */
+      const int tshift = 15 - 8 - (l + 2);
+      double e = (double)(1 << 15);
+      e = e * ldexp(1.0, -2 * tshift);
+      e = e / quant_scales[rem] / quant_scales[rem] / 1;
+      p.err_scale[ch][l] = e;
+    }
+    /* rdFactor of sign-bit hiding, TComTrQuant.cpp:2444-2447 (lambda = m_dLambda of the component) */
+    const double invQ = (double)inv_quant_scales[rem];
+    const double lam = p.rdoq_lambda[ch ? 1 : 0];
+    p.rd_factor[ch] = (long long)(invQ * invQ * (double)(1 << (2 * per)) / lam / 16 / 1 + 0.5);
+  }
+}
+
+inline void default_frame_params(fcu_frame_params &fp, int qp)
+{
+  memset(&fp, 0, sizeof(fp));
+  fp.qp = qp; fp.slice_ctus = 0; fp.transform_skip = 1; fp.transform_skip_fast = 1; fp.sign_hiding = 1; fp.strong_intra_smoothing = 1;
+}
+
+} // namespace fcu

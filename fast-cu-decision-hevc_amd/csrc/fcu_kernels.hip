@@ -1,0 +1,177 @@
+/*
+ * fcu_kernels.hip -- gfx950 kernel entry + the C ABI of libfcu.so (include/fcu.h).
+ *
+ * Launch geometry: one 64-thread workgroup (= one wavefront) per chain, grid = number of
+ * chains advanced by the call.  Chains are dealt round-robin over the 8 XCDs by the
+ * dispatcher; a chain's scratch (fcu::Scratch, ~0.7 MB) is touched only by its own wave,
+ * so it stays in that XCD's L2 / the Infinity Cache with no cross-XCD traffic.  All CABAC
+ * snapshots, reference samples and the SATD staging buffer live in LDS (fcu::Shared, 16 KB).
+ *
+ * There is no CPU fallback: every entry point returns FCU_ERR_NO_DEVICE without a GPU.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "fcu_host.h"
+
+using namespace fcu;
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FCU_WAVES_PER_EU, FCU_WAVES_PER_EU)))
+fcu_ctu_engine(Chain *chains, Scratch *scratch, int first, int ctus)
+{
+  __shared__ Shared S;
+  Chain *C = &chains[first + blockIdx.x];
+  Scratch *G = &scratch[first + blockIdx.x];
+  for (int k = 0; k < ctus; k++) {
+    const int a = C->next_ctu;
+    if (a >= C->n_ctu || C->out == nullptr) break;          /* every wave reaches this exit */
+    compress_ctu(C, G, &S, a);
+    FCU_SERIAL { C->next_ctu = a + 1; }
+  }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+struct fcu_ctx {
+  fcu_seq_params sp;
+  int n_ctu;
+  Chain *d_chains; Scratch *d_scratch;
+  std::vector<Chain> h_chains;
+  std::vector<int> h_pos;
+  std::vector<hipEvent_t> ev;      /* start/stop pairs of launches not yet harvested */
+  double ms_acc; int launches;
+};
+
+static char g_err[256] = "";
+static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #x, hipGetErrorString(e_)); return FCU_ERR_HIP; } } while (0)
+
+extern "C" {
+
+const char *fcu_last_error(void) { return g_err; }
+
+void fcu_default_frame_params(fcu_frame_params *fp, int qp) { default_frame_params(*fp, qp); }
+
+int fcu_create(const fcu_seq_params *sp, fcu_ctx **out)
+{
+  if (!sp || !out || sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7) || sp->max_chains <= 0) return fail(FCU_ERR_ARG, "bad sequence parameters");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || sp->device >= ndev) return fail(FCU_ERR_NO_DEVICE, "no HIP device: libfcu has no CPU fallback");
+  HIPCHK(hipSetDevice(sp->device));
+  fcu_ctx *c = new fcu_ctx();
+  c->sp = *sp; c->n_ctu = ((sp->width + 63) / 64) * ((sp->height + 63) / 64);
+  c->ms_acc = 0; c->launches = 0;
+  HIPCHK(hipMalloc((void **)&c->d_chains, sizeof(Chain) * (size_t)sp->max_chains));
+  HIPCHK(hipMalloc((void **)&c->d_scratch, sizeof(Scratch) * (size_t)sp->max_chains));
+  HIPCHK(hipMemset(c->d_chains, 0, sizeof(Chain) * (size_t)sp->max_chains));
+  c->h_chains.resize((size_t)sp->max_chains);
+  memset(c->h_chains.data(), 0, sizeof(Chain) * (size_t)sp->max_chains);
+  c->h_pos.assign((size_t)sp->max_chains, 0);
+  *out = c;
+  return FCU_OK;
+}
+
+void fcu_destroy(fcu_ctx *c)
+{
+  if (!c) return;
+  hipSetDevice(c->sp.device);
+  hipDeviceSynchronize();
+  for (hipEvent_t e : c->ev) hipEventDestroy(e);
+  hipFree(c->d_chains); hipFree(c->d_scratch);
+  delete c;
+}
+
+int fcu_num_ctus(const fcu_ctx *c) { return c ? c->n_ctu : 0; }
+
+int fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
+                    const uint8_t *oy, const uint8_t *ou, const uint8_t *ov, uint8_t *ry, uint8_t *ru, uint8_t *rv, fcu_ctu_out *dev_out)
+{
+  if (!c || !fp || chain < 0 || chain >= c->sp.max_chains || !oy || !ou || !ov || !ry || !ru || !rv || !dev_out) return fail(FCU_ERR_ARG, "fcu_chain_begin: bad argument");
+  if (fp->qp < 0 || fp->qp > 51 || fp->slice_ctus < 0) return fail(FCU_ERR_ARG, "fcu_chain_begin: QP / slice_ctus out of range");
+  HIPCHK(hipSetDevice(c->sp.device));
+  Chain &h = c->h_chains[(size_t)chain];
+  memset(&h, 0, sizeof(h));
+  fill_params(h.p, c->sp.width, c->sp.height, *fp);
+  h.org[0] = oy; h.org[1] = ou; h.org[2] = ov; h.rec[0] = ry; h.rec[1] = ru; h.rec[2] = rv;
+  h.stride[0] = c->sp.width; h.stride[1] = h.stride[2] = c->sp.width / 2;
+  h.out = dev_out;
+  h.w_ctu = (c->sp.width + 63) / 64; h.h_ctu = (c->sp.height + 63) / 64; h.n_ctu = h.w_ctu * h.h_ctu;
+  h.next_ctu = 0;
+  c->h_pos[(size_t)chain] = 0;
+  HIPCHK(hipMemcpy(&c->d_chains[chain], &h, sizeof(Chain), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+int fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream)
+{
+  if (!c || first < 0 || n <= 0 || first + n > c->sp.max_chains || ctus <= 0) return fail(FCU_ERR_ARG, "fcu_compress_chains: bad range");
+  for (int i = first; i < first + n; i++) if (c->h_chains[(size_t)i].out == nullptr) return fail(FCU_ERR_STATE, "fcu_compress_chains: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(fcu_ctu_engine, dim3((unsigned)n), dim3(64), 0, st, c->d_chains, c->d_scratch, first, ctus);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e1, st));
+  c->ev.push_back(e0); c->ev.push_back(e1);
+  for (int i = first; i < first + n; i++) { int &p = c->h_pos[(size_t)i]; p += ctus; if (p > c->n_ctu) p = c->n_ctu; }
+  return FCU_OK;
+}
+
+int fcu_sync(fcu_ctx *c)
+{
+  if (!c) return fail(FCU_ERR_ARG, "null ctx");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  return FCU_OK;
+}
+
+double fcu_kernel_ms(fcu_ctx *c, int *launches)
+{
+  if (!c) return 0.0;
+  hipSetDevice(c->sp.device);
+  hipDeviceSynchronize();
+  for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) { c->ms_acc += ms; c->launches++; }
+    hipEventDestroy(c->ev[i]); hipEventDestroy(c->ev[i + 1]);
+  }
+  c->ev.clear();
+  const int n = c->launches; const double avg = n ? c->ms_acc / n : 0.0;
+  if (launches) *launches = n;
+  c->ms_acc = 0; c->launches = 0;
+  return avg;
+}
+
+int fcu_chain_position(fcu_ctx *c, int chain)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains) return -1;
+  return c->h_pos[(size_t)chain];
+}
+
+int fcu_compress_ctu(fcu_ctx *c, int chain, uint32_t ctuRsAddr, fcu_ctu_out *host_out)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !host_out) return fail(FCU_ERR_ARG, "fcu_compress_ctu: bad argument");
+  if ((int)ctuRsAddr != c->h_pos[(size_t)chain] || (int)ctuRsAddr >= c->n_ctu) return fail(FCU_ERR_STATE, "fcu_compress_ctu: CTUs of a chain must be decided in raster order");
+  int r = fcu_compress_chains(c, chain, 1, 1, nullptr);
+  if (r != FCU_OK) return r;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host_out, c->h_chains[(size_t)chain].out + ctuRsAddr, sizeof(fcu_ctu_out), hipMemcpyDeviceToHost));
+  return FCU_OK;
+}
+
+int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bits)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !ctx160 || !frac_bits) return fail(FCU_ERR_ARG, "fcu_get_ctx_state: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  Chain h;
+  HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
+  memcpy(ctx160, h.state.ctx, NCTX);
+  *frac_bits = h.state.frac;
+  return FCU_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,198 @@
+"""Host side of the engine: ctypes binding of libfcu.so and a `TEncCu`-shaped class.
+
+The reference boundary is the C++ class `TEncCu` (Lib/TLibEncoder/TEncCu.h:104-118):
+create / init / compressCtu / encodeCtu / destroy, called once per CTU by
+`TEncSlice::compressSlice` (TEncSlice.cpp:1380-1551).  `CuEngine` keeps those names and
+their meaning; the batched form (`compress_chains`) is what a throughput-oriented caller uses.
+
+torch is plumbing only (device buffers, streams); the arithmetic is in the HIP kernels.
+The module raises if libfcu.so is missing or no GPU is present: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NPART = 256
+
+
+class FcuError(RuntimeError):
+    pass
+
+
+class FrameParams(C.Structure):
+    """fcu_frame_params (include/fcu.h)."""
+    _fields_ = [("qp", C.c_int), ("slice_ctus", C.c_int), ("transform_skip", C.c_int),
+                ("transform_skip_fast", C.c_int), ("sign_hiding", C.c_int), ("strong_intra_smoothing", C.c_int),
+                ("lambda_", C.c_double), ("sqrt_lambda", C.c_double), ("chroma_weight", C.c_double),
+                ("rdoq_lambda", C.c_double * 3)]
+
+
+class SeqParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("max_chains", C.c_int), ("device", C.c_int)]
+
+
+class CtuOut(C.Structure):
+    """fcu_ctu_out: the TComDataCU arrays published by copyToPic (TComDataCU.h:72-164)."""
+    _fields_ = [("depth", C.c_uint8 * NPART), ("width", C.c_uint8 * NPART), ("height", C.c_uint8 * NPART),
+                ("skip", C.c_uint8 * NPART), ("part_size", C.c_int8 * NPART), ("pred_mode", C.c_int8 * NPART),
+                ("tq_bypass", C.c_uint8 * NPART), ("qp", C.c_int8 * NPART), ("chroma_qp_adj", C.c_uint8 * NPART),
+                ("tr_idx", C.c_uint8 * NPART), ("tskip", (C.c_uint8 * NPART) * 3), ("cbf", (C.c_uint8 * NPART) * 3),
+                ("intra_dir", (C.c_uint8 * NPART) * 2), ("ipcm", C.c_uint8 * NPART),
+                ("coeff_y", C.c_int32 * 4096), ("coeff_cb", C.c_int32 * 1024), ("coeff_cr", C.c_int32 * 1024),
+                ("total_cost", C.c_double), ("total_dist", C.c_uint32), ("total_bits", C.c_uint32),
+                ("total_bins", C.c_uint32)]
+
+
+CTU_OUT_BYTES = C.sizeof(CtuOut)
+
+EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
+           "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
+           "fcu_kernel_ms", "fcu_last_error"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfcu.so")
+
+
+_lib = None
+
+
+def load_lib():
+    """Loads libfcu.so (the HIP extension).  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise FcuError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    lib.fcu_create.argtypes = [C.POINTER(SeqParams), C.POINTER(C.c_void_p)]
+    lib.fcu_destroy.argtypes = [C.c_void_p]
+    lib.fcu_num_ctus.argtypes = [C.c_void_p]
+    lib.fcu_default_frame_params.argtypes = [C.POINTER(FrameParams), C.c_int]
+    lib.fcu_chain_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameParams)] + [C.c_void_p] * 7
+    lib.fcu_compress_chains.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.fcu_compress_ctu.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(CtuOut)]
+    lib.fcu_get_ctx_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.fcu_chain_position.argtypes = [C.c_void_p, C.c_int]
+    lib.fcu_sync.argtypes = [C.c_void_p]
+    lib.fcu_kernel_ms.restype = C.c_double
+    lib.fcu_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.fcu_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def ctu_to_dict(c):
+    out = {}
+    for name, _ in CtuOut._fields_:
+        v = getattr(c, name)
+        out[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
+    return out
+
+
+class CuEngine:
+    """`TEncCu` stand-in for a set of independent chains (frames / slices) on one GPU.
+
+    create()        <- TEncCu::create  : allocates the per-chain device scratch
+    init_chain()    <- TEncCu::init + TEncSlice::setUpLambda : binds planes, QP, lambda
+    compress_ctu()  <- TEncCu::compressCtu + encodeCtu : one CTU of one chain, result to host
+    compress_chains(): the batched form, many chains x k CTUs per launch
+    destroy()       <- TEncCu::destroy
+    """
+
+    def __init__(self, width, height, max_chains=1, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise FcuError("no GPU visible: the CU engine has no CPU fallback")
+        self.torch = torch
+        self.lib = load_lib()
+        self.width, self.height, self.max_chains, self.device = width, height, max_chains, device
+        self.h = C.c_void_p()
+        self._keep = {}
+        self.create()
+
+    # -- TEncCu::create
+    def create(self):
+        sp = SeqParams(self.width, self.height, self.max_chains, self.device)
+        r = self.lib.fcu_create(C.byref(sp), C.byref(self.h))
+        if r != 0:
+            raise FcuError(f"fcu_create failed ({r}): {self.lib.fcu_last_error().decode()}")
+        self.n_ctu = self.lib.fcu_num_ctus(self.h)
+
+    def _chk(self, r, what):
+        if r != 0:
+            raise FcuError(f"{what} failed ({r}): {self.lib.fcu_last_error().decode()}")
+
+    # -- TEncCu::init + slice parameters
+    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, **flags):
+        """org: (Y,U,V) uint8 torch tensors on this device (or numpy arrays, uploaded once)."""
+        torch = self.torch
+        dev = torch.device("cuda", self.device)
+        planes = []
+        for a in org:
+            t = torch.as_tensor(a) if not torch.is_tensor(a) else a
+            planes.append(t.to(device=dev, dtype=torch.uint8).contiguous())
+        if rec is None:
+            rec = [torch.zeros_like(p) for p in planes]
+        if out is None:
+            out = torch.zeros(self.n_ctu * CTU_OUT_BYTES, dtype=torch.uint8, device=dev)
+        fp = FrameParams()
+        self.lib.fcu_default_frame_params(C.byref(fp), qp)
+        fp.slice_ctus = slice_ctus
+        for k, v in flags.items():
+            setattr(fp, k, v)
+        self._chk(self.lib.fcu_chain_begin(self.h, chain, C.byref(fp), *[p.data_ptr() for p in planes],
+                                           *[p.data_ptr() for p in rec], out.data_ptr()), "fcu_chain_begin")
+        self._keep[chain] = (planes, rec, out)
+        return rec, out
+
+    # -- TEncCu::compressCtu (+ encodeCtu replay)
+    def compress_ctu(self, chain, ctu_rs_addr):
+        c = CtuOut()
+        self._chk(self.lib.fcu_compress_ctu(self.h, chain, ctu_rs_addr, C.byref(c)), "fcu_compress_ctu")
+        return ctu_to_dict(c)
+
+    def compress_chains(self, first, n, ctus, stream=None):
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._chk(self.lib.fcu_compress_chains(self.h, first, n, ctus, s), "fcu_compress_chains")
+
+    def sync(self):
+        self._chk(self.lib.fcu_sync(self.h), "fcu_sync")
+
+    def kernel_ms(self):
+        n = C.c_int(0)
+        ms = self.lib.fcu_kernel_ms(self.h, C.byref(n))
+        return ms, n.value
+
+    def position(self, chain):
+        return self.lib.fcu_chain_position(self.h, chain)
+
+    def ctx_state(self, chain):
+        ctx = np.zeros(160, np.uint8)
+        frac = C.c_uint64(0)
+        self._chk(self.lib.fcu_get_ctx_state(self.h, chain, ctx.ctypes.data, C.byref(frac)), "fcu_get_ctx_state")
+        return ctx, int(frac.value)
+
+    def rec_planes(self, chain):
+        return [p.cpu().numpy() for p in self._keep[chain][1]]
+
+    def ctu_out(self, chain, ctu_rs_addr):
+        buf = self._keep[chain][2][ctu_rs_addr * CTU_OUT_BYTES:(ctu_rs_addr + 1) * CTU_OUT_BYTES].cpu().numpy()
+        return ctu_to_dict(CtuOut.from_buffer_copy(buf.tobytes()))
+
+    # -- TEncCu::destroy
+    def destroy(self):
+        if self.h:
+            self.lib.fcu_destroy(self.h)
+            self.h = C.c_void_p()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -29,3 +29,27 @@ def textured(width, height, seed=7):
     V = 128 + 25 * np.cos(cy / 19) + rng.normal(0, 5, cy.shape)
     f = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
     return f(Y), f(U), f(V)
+
+
+def mixed(width, height, seed=7):
+    """Piecewise content (flat blocks of 4..64 px, ramps, sharp text-like edges, mild noise):
+    drives decisions through all CU depths, NxN, RQT splits and transform skip."""
+    rng = np.random.default_rng(seed)
+    Y = np.zeros((height, width), np.float64)
+    for bs in (64, 32, 16, 8, 4):
+        gy, gx = (height + bs - 1) // bs, (width + bs - 1) // bs
+        lvl = rng.integers(16, 235, (gy, gx)).astype(np.float64)
+        mask = rng.random((gy, gx)) < (0.55 if bs == 64 else 0.3)
+        up = np.kron(lvl, np.ones((bs, bs)))[:height, :width]
+        m = np.kron(mask, np.ones((bs, bs)))[:height, :width] > 0
+        if bs == 64:
+            Y = up
+        else:
+            Y = np.where(m, up, Y)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    Y = Y + 12 * np.sin(x / 5.0) * (((x // 48) + (y // 40)) % 3 == 0) + rng.normal(0, 1.5, (height, width))
+    cy, cx = np.mgrid[0:height // 2, 0:width // 2].astype(np.float64)
+    U = 128 + 0.35 * (Y[::2, ::2] - 128) * (((cx // 24) % 2) * 2 - 1) + rng.normal(0, 1.0, cy.shape)
+    V = 128 + 30 * np.sin(cx / 13 + cy / 29) + 40 * ((cy // 8 + cx // 8) % 5 == 0) + rng.normal(0, 1.0, cy.shape)
+    f = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    return f(Y), f(U), f(V)

@@ -1,0 +1,98 @@
+/*
+ * fcu.h -- C ABI of the MI355X CU-decision engine (libfcu.so).
+ *
+ * Drop-in boundary for HM's `TEncCu` (reference: Lib/TLibEncoder/TEncCu.h:104-118):
+ *
+ *   reference entry point                         replacement
+ *   -------------------------------------------   ------------------------------------------
+ *   TEncCu::create  (TEncCu.cpp:163)              fcu_create
+ *   TEncCu::destroy (TEncCu.cpp:214)              fcu_destroy
+ *   TEncCu::init + TEncSlice::setUpLambda         fcu_chain_begin   (per slice-chain parameters,
+ *     (TEncCu.cpp:306, TEncSlice.cpp:496-524)                        lambda as f64 bit patterns)
+ *   TEncCu::compressCtu (TEncCu.cpp:329)          fcu_compress_ctu  (one CTU of one chain) /
+ *     + TEncCu::encodeCtu context replay          fcu_compress_chains (batched, many chains)
+ *     (TEncCu.cpp:359, TEncSlice.cpp:1468-1487)
+ *   m_pppcRDSbacCoder[0][CI_CURR_BEST] state      fcu_get_ctx_state
+ *     (TEncSlice.cpp:1417,1477)
+ *
+ * Plain pointers and sizes only; no torch / HIP types.  All `dev_*` pointers are device
+ * (HBM) addresses owned by the caller; planes are 8-bit 4:2:0 (HM's int16 `Pel` planes are
+ * narrowed by the adapter).  The library FAILS (returns FCU_ERR_NO_DEVICE)
+ * when no HIP device is present: there is no CPU fallback.
+ */
+#ifndef FCU_H
+#define FCU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCU_NPART 256            /* 4x4 partitions per 64x64 CTU, z-order (TComDataCU) */
+
+enum { FCU_OK = 0, FCU_ERR_NO_DEVICE = -1, FCU_ERR_ARG = -2, FCU_ERR_HIP = -3, FCU_ERR_STATE = -4 };
+
+/* Per-CTU result: the TComDataCU arrays that copyToPic publishes (TComDataCU.h:72-164,
+ * TComDataCU.cpp:992-1065).  One entry per 4x4 luma partition, z-order.  Coefficients are
+ * TU-contiguous at offset absPartIdx*16 (luma) / absPartIdx*4 (chroma) like m_pcTrCoeff. */
+typedef struct fcu_ctu_out {
+  uint8_t  depth[FCU_NPART], width[FCU_NPART], height[FCU_NPART];   /* m_puhDepth/Width/Height */
+  uint8_t  skip[FCU_NPART];                                         /* m_skipFlag              */
+  int8_t   part_size[FCU_NPART], pred_mode[FCU_NPART];              /* m_pePartSize/PredMode   */
+  uint8_t  tq_bypass[FCU_NPART];                                    /* m_CUTransquantBypass    */
+  int8_t   qp[FCU_NPART];                                           /* m_phQP                  */
+  uint8_t  chroma_qp_adj[FCU_NPART];                                /* m_ChromaQpAdj           */
+  uint8_t  tr_idx[FCU_NPART];                                       /* m_puhTrIdx              */
+  uint8_t  tskip[3][FCU_NPART];                                     /* m_puhTransformSkip      */
+  uint8_t  cbf[3][FCU_NPART];                                       /* m_puhCbf (bit t = depth t) */
+  uint8_t  intra_dir[2][FCU_NPART];                                 /* m_puhIntraDir           */
+  uint8_t  ipcm[FCU_NPART];                                         /* m_pbIPCMFlag            */
+  int32_t  coeff_y[4096], coeff_cb[1024], coeff_cr[1024];           /* m_pcTrCoeff             */
+  double   total_cost;                                              /* m_dTotalCost            */
+  uint32_t total_dist, total_bits, total_bins;                      /* m_uiTotal*              */
+} fcu_ctu_out;
+
+typedef struct fcu_seq_params {
+  int width, height;             /* luma samples, multiples of 8 (SPS)                       */
+  int max_chains;                /* chains (frame/slice sequences) decided concurrently      */
+  int device;                    /* HIP device ordinal                                       */
+} fcu_seq_params;
+
+typedef struct fcu_frame_params {
+  int qp;                        /* slice QP                                                 */
+  int slice_ctus;                /* SliceMode 1 / SliceArgument (CTUs per slice); 0 = 1 slice */
+  int transform_skip, transform_skip_fast, sign_hiding, strong_intra_smoothing;
+  /* 0.0 => derive as HM does for an I slice (TEncSlice.cpp:686-706, 496-524) */
+  double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
+} fcu_frame_params;
+
+typedef struct fcu_ctx fcu_ctx;
+
+void fcu_default_frame_params(fcu_frame_params *fp, int qp);
+int  fcu_create(const fcu_seq_params *sp, fcu_ctx **out);
+void fcu_destroy(fcu_ctx *c);
+int  fcu_num_ctus(const fcu_ctx *c);
+/* Bind a chain to its planes/output and reset it to CTU 0.  dev_out holds fcu_num_ctus() entries. */
+int  fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
+                     const uint8_t *dev_org_y, const uint8_t *dev_org_u, const uint8_t *dev_org_v,
+                     uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
+                     fcu_ctu_out *dev_out);
+/* Advance chains [first, first+n) by up to `ctus` CTUs each (raster order; compressCtu +
+ * encodeCtu replay per CTU).  Asynchronous on `hip_stream` (hipStream_t or NULL). */
+int  fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream);
+/* HM-shaped call: decide CTU `ctuRsAddr` (must be the chain's next CTU) and copy its
+ * TComDataCU arrays to host memory.  Synchronous. */
+int  fcu_compress_ctu(fcu_ctx *c, int chain, uint32_t ctuRsAddr, fcu_ctu_out *host_out);
+/* context state of m_pppcRDSbacCoder[0][CI_CURR_BEST] after the chain's last CTU:
+ * 160 context bytes (engine order, see fcu_engine.h) + the Q15 fractional bit counter */
+int  fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bits);
+int  fcu_chain_position(fcu_ctx *c, int chain);          /* next CTU to be decided */
+int  fcu_sync(fcu_ctx *c);
+/* average duration (ms) of the engine kernel launches recorded with HIP events on the launch
+ * stream since the last call; resets the accumulator */
+double fcu_kernel_ms(fcu_ctx *c, int *launches);
+const char *fcu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,37 @@
+/*
+ * fcu_emu.cpp -- TEST-ONLY build of the engine source as a plain C++ wave emulator
+ * (-DFCU_EMU: the 64 lanes of each phase run as a loop).  It exists so that the engine's
+ * decision logic can be compared with the oracle in `-m "not gpu"` tests where no GPU is
+ * present.  It is NOT part of libfcu.so and nothing in the product path can reach it.
+ */
+#define FCU_EMU 1
+#include "../../fast-cu-decision-hevc_amd/csrc/fcu_host.h"
+#include <stdlib.h>
+#include <new>
+
+using namespace fcu;
+
+struct EmuChain { Chain c; Scratch *g; Shared *s; };
+
+extern "C" {
+void *fcu_emu_create(int width, int height, int qp, int slice_ctus, const uint8_t *oy, const uint8_t *ou, const uint8_t *ov,
+                     uint8_t *ry, uint8_t *ru, uint8_t *rv, fcu_ctu_out *out)
+{
+  EmuChain *e = new EmuChain();
+  memset(&e->c, 0, sizeof(e->c));
+  fcu_frame_params fp; default_frame_params(fp, qp); fp.slice_ctus = slice_ctus;
+  fill_params(e->c.p, width, height, fp);
+  e->c.org[0] = oy; e->c.org[1] = ou; e->c.org[2] = ov; e->c.rec[0] = ry; e->c.rec[1] = ru; e->c.rec[2] = rv;
+  e->c.stride[0] = width; e->c.stride[1] = e->c.stride[2] = width / 2;
+  e->c.out = out;
+  e->c.w_ctu = (width + 63) / 64; e->c.h_ctu = (height + 63) / 64; e->c.n_ctu = e->c.w_ctu * e->c.h_ctu;
+  e->g = (Scratch *)calloc(1, sizeof(Scratch));
+  e->s = (Shared *)calloc(1, sizeof(Shared));
+  return e;
+}
+void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); free(e->s); delete e; }
+void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, e->s, a); e->c.next_ctu = a + 1; }
+void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX); *frac = e->c.state.frac; }
+unsigned long long fcu_emu_tu_trials(void *h) { return ((EmuChain *)h)->c.n_tu_trials; }
+int fcu_emu_sizes(int which) { return which == 0 ? (int)sizeof(Scratch) : which == 1 ? (int)sizeof(Shared) : (int)sizeof(Chain); }
+}

@@ -1,0 +1,54 @@
+"""ctypes binding of tests/emu/libfcu_emu.so (TEST-ONLY wave emulator of the engine source)."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "..", "oracle"))
+from hmo_py import Ctu  # same TComDataCU layout as include/fcu.h:fcu_ctu_out
+
+
+def load():
+    lib = C.CDLL(os.path.join(_HERE, "emu", "libfcu_emu.so"))
+    lib.fcu_emu_create.restype = C.c_void_p
+    lib.fcu_emu_create.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7
+    lib.fcu_emu_destroy.argtypes = [C.c_void_p]
+    lib.fcu_emu_compress_ctu.argtypes = [C.c_void_p, C.c_int]
+    lib.fcu_emu_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_emu_tu_trials.restype = C.c_ulonglong
+    lib.fcu_emu_tu_trials.argtypes = [C.c_void_p]
+    return lib
+
+
+class EmuEncoder:
+    def __init__(self, Y, U, V, qp, slice_ctus=0):
+        self.lib = load()
+        h, w = Y.shape
+        self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
+        self.rec = [np.zeros_like(a) for a in self.org]
+        self.n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+        self.out = (Ctu * self.n_ctu)()
+        self.h = self.lib.fcu_emu_create(w, h, qp, slice_ctus, *[a.ctypes.data for a in self.org],
+                                         *[a.ctypes.data for a in self.rec], C.addressof(self.out))
+
+    def compress_ctu(self, a):
+        self.lib.fcu_emu_compress_ctu(self.h, a)
+
+    def compress_frame(self):
+        for a in range(self.n_ctu):
+            self.compress_ctu(a)
+
+    def ctu_arrays(self, a):
+        c = self.out[a]
+        res = {}
+        for name, _ in Ctu._fields_:
+            v = getattr(c, name)
+            res[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
+        return res
+
+    def cabac(self):
+        ctx = np.zeros(160, np.uint8)
+        frac = C.c_uint64(0)
+        self.lib.fcu_emu_get_state(self.h, ctx.ctypes.data, C.byref(frac))
+        return ctx, int(frac.value)
