@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- CTUs/sec of the CU depth/mode RDO decision (TEncCu::compressCtu equivalent).
+
+Workload (BASELINE.json configs[2]): 3840x2160 all-intra, QP {22,27,32,37}, full depth-0..3
+quadtree + chroma RDO, synthetic "textured" YUV, resident in HBM before the
+timed region.  A chain = (frame, QP) = one I slice, the unit HM decides strictly serially;
+`--frames` frames x 4 QPs chains run side by side, one wavefront each.  A *step* advances every
+chain by `--ctus-per-step` CTUs (compressCtu + encodeCtu replay per CTU) in one launch.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; every rank
+   owns its own frames -- no collective on the data path; weak scaling)
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 1024 + rec 12288 + coeff 24576 + meta 5120
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def gen_textured_gpu(torch, dev, w, h, seed):
+    """The SURVEY 8d 'textured' generator evaluated on the device (torch RNG)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
+    x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
+    noise = torch.randn((h, w), generator=g, device=dev) * 18 * (1 + ((x // 64 + y // 64) % 3)) / 2
+    Y = 128 + 50 * torch.sin(x / 9 + y / 31) + 35 * torch.cos(y / 7) * torch.sin(x / 53) + noise
+    cy = torch.arange(h // 2, device=dev, dtype=torch.float32)[:, None]
+    cx = torch.arange(w // 2, device=dev, dtype=torch.float32)[None, :]
+    U = 128 + 25 * torch.sin(cx / 23) + torch.randn((h // 2, w // 2), generator=g, device=dev) * 5 + 0 * cy
+    V = 128 + 25 * torch.cos(cy / 19) + torch.randn((h // 2, w // 2), generator=g, device=dev) * 5 + 0 * cx
+    f = lambda a: a.round().clamp(0, 255).to(torch.uint8).contiguous()
+    return f(Y), f(U), f(V)
+
+
+def cpu_baseline(frame_np, qp, budget_s=15.0):
+    """The oracle (plain-C restatement of the reference loop) on this box's host cores, 1 thread,
+    on the first CTUs of the same workload.  A reported baseline, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hmo_py
+    enc = hmo_py.Encoder(*frame_np, qp)
+    t0 = time.time()
+    n = 0
+    while n < enc.n_ctu and (time.time() - t0) < budget_s:
+        enc.compress_ctu(n)
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "CTUs/sec", "cores": 1, "kind": "port",
+            "sample": f"first {n} CTUs of frame 0 (3840x2160, QP{qp}), oracle/libhmo.so single thread, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU (x4 QPs = chains per GPU)")
+    ap.add_argument("--ctus-per-step", type=int, default=1)
+    ap.add_argument("--qps", default="22,27,32,37")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    qps = [int(q) for q in args.qps.split(",")]
+    W, H = args.width, args.height
+    n_chains = args.frames * len(qps)
+    total_ctus_chain = (args.warmup + args.steps) * args.ctus_per_step
+    eng = pkg.CuEngine(W, H, max_chains=n_chains, device=local)
+    assert total_ctus_chain <= eng.n_ctu, "bench walks past the end of the frame"
+    # inputs resident in HBM before timing; every chain gets its own reconstruction plane set,
+    # the 4 QP chains of a frame share its source planes
+    out_bytes = pkg.engine.CTU_OUT_BYTES * total_ctus_chain
+    frames, keep = [], []
+    for f in range(args.frames):
+        fr = gen_textured_gpu(torch, dev, W, H, seed=7 + f + 1000 * rank)
+        frames.append(fr)
+        for qi, qp in enumerate(qps):
+            rec = [torch.zeros_like(p) for p in fr]
+            out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+            eng.init_chain(f * len(qps) + qi, fr, qp=qp, rec=rec, out=out)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.compress_chains(0, n_chains, args.ctus_per_step)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.kernel_ms()                       # drop warm-up launches from the event accumulator
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms, launches = eng.kernel_ms()
+
+    ctus_per_step_gpu = n_chains * args.ctus_per_step
+    total = ctus_per_step_gpu * args.steps * world
+    value = total / dt
+    if rank == 0:
+        achieved = (ALGO_BYTES_PER_CTU * ctus_per_step_gpu) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        res = {
+            "metric": "CTUs/sec (RDO decision only) at 4K all-intra", "value": value, "unit": "CTUs/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO "
+                                   f"(BASELINE configs[2]); {args.frames} frames x {len(qps)} QPs = {n_chains} chains/GPU, "
+                                   f"{args.ctus_per_step} CTU/chain/step",
+                       "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches},
+        }
+        if not args.no_cpu_baseline:
+            fr0 = [p.cpu().numpy() for p in frames[0]]
+            res["cpu_baseline"] = cpu_baseline(fr0, 32)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    eng.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
