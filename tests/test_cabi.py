@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/fcu.h declares; without a GPU it
+fails loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "fcu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcu_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported(built, pkg):
+    lib = C.CDLL(pkg.lib_path())
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"libfcu.so does not export {s}"
+    assert sorted(pkg.engine.EXPORTS) == syms
+
+
+def test_struct_layouts_match_between_binding_and_oracle(built, pkg):
+    import hmo_py
+    assert C.sizeof(pkg.engine.CtuOut) == C.sizeof(hmo_py.Ctu)
+    for (n1, _), (n2, _) in zip(pkg.engine.CtuOut._fields_, hmo_py.Ctu._fields_):
+        assert n1 == n2
+        assert getattr(pkg.engine.CtuOut, n1).offset == getattr(hmo_py.Ctu, n2).offset
+
+
+def test_no_gpu_means_loud_failure(built, pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = pkg.load_lib()
+    sp = pkg.engine.SeqParams(128, 64, 1, 0)
+    h = C.c_void_p()
+    r = lib.fcu_create(C.byref(sp), C.byref(h))
+    assert r == -1 and not h.value                      # FCU_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.fcu_last_error()
+    with pytest.raises(pkg.FcuError):
+        pkg.CuEngine(128, 64)
+
+
+def test_bad_arguments_are_rejected(built, pkg):
+    lib = pkg.load_lib()
+    h = C.c_void_p()
+    sp = pkg.engine.SeqParams(130, 64, 1, 0)            # width not a multiple of the minimum CU size
+    assert lib.fcu_create(C.byref(sp), C.byref(h)) == -2
+    assert lib.fcu_chain_position(None, 0) == -1
