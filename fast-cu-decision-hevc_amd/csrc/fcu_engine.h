@@ -29,12 +29,14 @@
 #include <math.h>
 #include <stdlib.h>
 #define FCU_DEV static inline
+#define FCU_NOINLINE
 #define FCU_TABLE static const
 #define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
 #define FCU_FLOOR(x) floor(x)
 #else
 #define FCU_DEV __device__ static
+#define FCU_NOINLINE __noinline__
 #define FCU_TABLE __device__ static const
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
@@ -55,7 +57,7 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
        CTX_TSKIP = 157, NCTX = 160 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
-enum { MAXVC = 20, POOL = 5120, DIFFN = 2048 };
+enum { MAXVC = 20, POOL = 5120, DIFFN = 1024 };
 #define FCU_MAX_DOUBLE 1.7e+308
 
 /* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
@@ -114,7 +116,7 @@ struct Shared {
   Cabac lane[MAXVC];
   uint8_t ref[264], reff[264];
   int16_t diff[DIFFN];
-  int32_t colsum[512];
+  int32_t colsum[256];
   uint32_t sad[36];
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
@@ -261,7 +263,7 @@ FCU_DEV void code_coef_remain(Cabac *c, uint32_t symbol, uint32_t rparam)      /
   }
 }
 /* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535 */
-FCU_DEV void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P)
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   int numSig = 0;
@@ -385,7 +387,7 @@ FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, d
 }
 /* `c` is the coder whose contexts estBit() would snapshot (TEncSbac.cpp:1722-1956); cbfCtx
  * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset). Returns uiAbsSum. */
-FCU_DEV int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
+FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
                  const Params &P, const RdoqBuf &rb)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
@@ -637,7 +639,7 @@ FCU_DEV int unit_available(const Env &E, int lx, int ly, int cx, int cy)
 
 /* Reference samples of a block (initAdiPatternChType + fillReferenceSamples + smoothing,
  * TComPattern.cpp:104-521) -> S->ref (unfiltered), S->reff (filtered, luma only), S->dc. */
-FCU_DEV void build_ref(const Env &E, int comp, int px, int py, int log2, int wantFilt)
+FCU_DEV FCU_NOINLINE void build_ref(const Env &E, int comp, int px, int py, int log2, int wantFilt)
 {
   Shared *S = E.S;
   const int N = 1 << log2, sh = comp ? 1 : 0, unit = 4 >> sh, total = 4 * N + 1;
@@ -768,7 +770,7 @@ FCU_DEV void code_luma_dir_bits(Cabac *c, int dir, const int *preds)
   cab_bin(c, predIdx != -1, CTX_INTRA_LUMA);
   cab_ep(c, predIdx != -1 ? (predIdx ? 2 : 1) : 5);
 }
-FCU_DEV void code_intra_dir_luma(const Env &E, Cabac *c, const CuObj *cu, int part, int multiple)
+FCU_DEV FCU_NOINLINE void code_intra_dir_luma(const Env &E, Cabac *c, const CuObj *cu, int part, int multiple)
 {
   int preds[4][3], predIdx[4];
   const int partNum = multiple ? (cu->part_size[part] == SIZE_NxN ? 4 : 1) : 1;
@@ -787,7 +789,7 @@ FCU_DEV void code_intra_dir_chroma(Cabac *c, int dir)       /* TEncSbac.cpp:698-
 FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
 
 /* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
-FCU_DEV void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int bLuma, int bChroma)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -814,7 +816,7 @@ FCU_DEV void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj *cu, const TU
   }
   (void)E;
 }
-FCU_DEV void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int comp, int realCoeff)
+FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int comp, int realCoeff)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -846,7 +848,7 @@ FCU_DEV void enc_intra_header(const Env &E, Cabac *c, const CuObj *cu, int trDep
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
-FCU_DEV uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &tu, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &tu, int bLuma, int bChroma)
 {
   cab_reset_bits(c);
   enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
@@ -857,7 +859,7 @@ FCU_DEV uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj *cu, const TU
 }
 
 /* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
-FCU_DEV void encode_transform(const Env &E, Cabac *c, const CuObj *cu, int cuPart, const TU &root)
+FCU_DEV FCU_NOINLINE void encode_transform(const Env &E, Cabac *c, const CuObj *cu, int cuPart, const TU &root)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -907,7 +909,7 @@ FCU_DEV void encode_cu_syntax(const Env &E, Cabac *c, const CuObj *cu, int cuPar
 /* ======================================================================================== */
 /* CU object helpers (cooperative)                                                           */
 /* ======================================================================================== */
-FCU_DEV void cu_init(const Env &E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
+FCU_DEV FCU_NOINLINE void cu_init(const Env &E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
 {
   const int n = NPART >> (2 * depth), s = CTU >> depth;
   FCU_FOR_LANES {
@@ -922,7 +924,7 @@ FCU_DEV void cu_init(const Env &E, CuObj *cu, int depth, int x, int y, int zidx)
   }
   (void)E;
 }
-FCU_DEV void cu_copy_part_from(const Env &E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
+FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env &E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
 {
   const int n = src->nparts, off = partUnitIdx * n;
   FCU_FOR_LANES {
@@ -938,7 +940,7 @@ FCU_DEV void cu_copy_part_from(const Env &E, CuObj *dst, const CuObj *src, int p
   }
   (void)E;
 }
-FCU_DEV void cu_copy_to_pic(const Env &E, const CuObj *cu)                             /* copyToPic */
+FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env &E, const CuObj *cu)                             /* copyToPic */
 {
   fcu_ctu_out *p = &E.C->out[E.cur_ctu];
   const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
@@ -955,7 +957,7 @@ FCU_DEV void cu_copy_to_pic(const Env &E, const CuObj *cu)                      
     for (int i = lane; i < n * 4; i += 64) { p->coeff_cb[off * 4 + i] = cu->coef[1][i]; p->coeff_cr[off * 4 + i] = cu->coef[2][i]; }
   }
 }
-FCU_DEV void copy_reco_to_pic(const Env &E, const Yuv *r, int x, int y, int s)
+FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env &E, const Yuv *r, int x, int y, int s)
 {
   FCU_FOR_LANES {
     for (int c = 0; c < 3; c++) {
@@ -971,7 +973,7 @@ FCU_DEV void copy_reco_to_pic(const Env &E, const Yuv *r, int x, int y, int s)
 /* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
 /* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
 /* ======================================================================================== */
-FCU_DEV void tu_trial(const Env &E, CuObj *cu, const TU &tu, int comp, Cabac *cab, int save1load2)
+FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int comp, Cabac *cab, int save1load2)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   if (comp && tu.cw == 0) { FCU_SERIAL { S->t_dist = 0; S->t_abs = 0; } return; }
@@ -1054,7 +1056,7 @@ FCU_DEV void tu_trial(const Env &E, CuObj *cu, const TU &tu, int comp, Cabac *ca
 }
 
 /* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
-FCU_DEV void store_intra_result_qt(const Env &E, const TU &tu, int comp)
+FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env &E, const TU &tu, int comp)
 {
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
@@ -1063,7 +1065,7 @@ FCU_DEV void store_intra_result_qt(const Env &E, const TU &tu, int comp)
   const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
   FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
 }
-FCU_DEV void load_intra_result_qt(const Env &E, const CuObj *cu, const TU &tu, int comp)
+FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env &E, const CuObj *cu, const TU &tu, int comp)
 {
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
@@ -1079,7 +1081,7 @@ FCU_DEV void load_intra_result_qt(const Env &E, const CuObj *cu, const TU &tu, i
 /* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to S->q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
@@ -1158,7 +1160,7 @@ FCU_DEV void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
-FCU_DEV void set_intra_result_luma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)
+FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)
 {
   Scratch *G = E.G;
   TU st[4]; int ci[4]; int sp = 0;
@@ -1188,7 +1190,7 @@ FCU_DEV void set_intra_result_luma_qt(const Env &E, CuObj *cu, const TU &root, Y
 /* RMD: 35 predictions + Hadamard SATD staged through LDS (TEncSearch.cpp:2300-2361,          */
 /* TComRdCost.cpp:1343-1604) and the sorted candidate list (xUpdateCandList :5345-5370)       */
 /* ======================================================================================== */
-FCU_DEV void rmd(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
@@ -1270,7 +1272,7 @@ FCU_DEV void rmd(const Env &E, CuObj *cu, const TU &tu)
 /* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
 /* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
 /* ======================================================================================== */
-FCU_DEV void pu_first_pass_batched(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const TU &tu)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
@@ -1373,7 +1375,7 @@ FCU_DEV void pu_first_pass_batched(const Env &E, CuObj *cu, const TU &tu)
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
-FCU_DEV void est_intra_pred_luma(const Env &E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
 {
   Shared *S = E.S; Scratch *G = E.G;
   const int d = cu->depth_cu, partSize = cu->part_size[0];
@@ -1441,7 +1443,7 @@ FCU_DEV void est_intra_pred_luma(const Env &E, CuObj *cu)
 /* chroma: xRecurIntraChromaCodingQT / estIntraPredChromaQT, TEncSearch.cpp:1916-2120,2661-2810 */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV void recur_chroma_qt(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV FCU_NOINLINE void recur_chroma_qt(const Env &E, CuObj *cu, const TU &tu)
 {
   Shared *S = E.S; const Params &P = E.C->p;
   const int part = tu.part, trDepth = tu.tr_depth;
@@ -1494,7 +1496,7 @@ FCU_DEV void recur_chroma_qt(const Env &E, CuObj *cu, const TU &tu)
     }
   }
 }
-FCU_DEV void set_intra_result_chroma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)   /* TEncSearch.cpp:2126-2175 */
+FCU_DEV FCU_NOINLINE void set_intra_result_chroma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)   /* TEncSearch.cpp:2126-2175 */
 {
   Scratch *G = E.G;
   TU st[4]; int ci[4]; int sp = 0;
@@ -1520,7 +1522,7 @@ FCU_DEV void set_intra_result_chroma_qt(const Env &E, CuObj *cu, const TU &root,
     { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
   }
 }
-FCU_DEV void est_intra_pred_chroma(const Env &E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, n = cu->nparts;
@@ -1557,7 +1559,7 @@ FCU_DEV void est_intra_pred_chroma(const Env &E, CuObj *cu)
 FCU_DEV CuObj *cu_best(const Env &E, int d) { return &E.G->cu[d][E.S->best_idx[d]]; }
 FCU_DEV CuObj *cu_temp(const Env &E, int d) { return &E.G->cu[d][1 - E.S->best_idx[d]]; }
 
-FCU_DEV void check_best_mode(const Env &E, int d)
+FCU_DEV FCU_NOINLINE void check_best_mode(const Env &E, int d)
 {
   Shared *S = E.S;
   const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
@@ -1565,7 +1567,7 @@ FCU_DEV void check_best_mode(const Env &E, int d)
     if (change) { cab_copy(&S->slot[d][CI_NEXT_BEST], &S->slot[d][CI_TEMP_BEST], lane); if (lane == 0) { S->best_idx[d] = 1 - S->best_idx[d]; S->reco_best_idx[d] = 1 - S->reco_best_idx[d]; } }
   }
 }
-FCU_DEV void check_rd_cost_intra(const Env &E, int d, int partSize)
+FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   CuObj *cu = cu_temp(E, d);
@@ -1590,7 +1592,7 @@ FCU_DEV void check_rd_cost_intra(const Env &E, int d, int partSize)
 }
 
 template <int D>
-FCU_DEV void compress_cu(const Env &E)
+FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const CuObj *b0 = cu_best(E, D);
@@ -1656,7 +1658,7 @@ FCU_DEV void compress_cu(const Env &E)
 }
 
 /* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */
-FCU_DEV void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, int lastCtuOfSlice)
+FCU_DEV FCU_NOINLINE void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, int lastCtuOfSlice)
 {
   const Params &P = E.C->p;
   int stPart[4], stChild[4]; int sp = 0;
@@ -1685,7 +1687,7 @@ FCU_DEV void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, int lastCtuOfS
 }
 
 /* ---- one CTU of one chain: the loop body of TEncSlice::compressSlice, TEncSlice.cpp:1380-1551 */
-FCU_DEV void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuRsAddr)
+FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuRsAddr)
 {
   Env E; E.C = C; E.G = G; E.S = S;
   const Params &P = C->p;

@@ -966,3 +966,99 @@ void hmo_compress_frame(HmoEnc *e)
 {
   for (int a = 0; a < e->n_ctu; a++) hmo_compress_ctu(e, a);
 }
+
+/* ====================================================================================
+ * leaf-level test entry points (compared with the reference's own leaf code through
+ * tests/golden/*.npz, see oracle/ref/)
+ * ================================================================================== */
+void hmo_test_begin(HmoEnc *e, int cur_ctu)
+{
+  e->cur_ctu = cur_ctu; e->slice_start = 0;
+  hmo_cabac_init(&e->goon, e->p.qp); e->goon_bins = 0;
+}
+/* field ids as oracle/ref/ref_driver.cpp:ref_set_ctu_field */
+void hmo_test_set_ctu_field(HmoEnc *e, int ctu, int field, const uint8_t *v)
+{
+  HmoCtu *c = &e->pic[ctu];
+  for (int i = 0; i < HMO_NPART; i++) {
+    switch (field) {
+      case 0: c->depth[i] = v[i]; break;
+      case 1: c->part_size[i] = (int8_t)v[i]; break;
+      case 2: c->pred_mode[i] = (int8_t)v[i]; break;
+      case 3: c->intra_dir[0][i] = v[i]; break;
+      case 4: c->intra_dir[1][i] = v[i]; break;
+      case 5: c->tr_idx[i] = v[i]; break;
+      default: break;
+    }
+  }
+}
+static void view_from_pic(const HmoEnc *e, int ctu, HmoCU *v)
+{
+  const HmoCtu *p = &e->pic[ctu];
+  v->depth_cu = 0; v->x = (ctu % e->w_ctu) * HMO_CTU; v->y = (ctu / e->w_ctu) * HMO_CTU; v->zidx = 0; v->nparts = HMO_NPART;
+  memcpy(v->depth, p->depth, HMO_NPART); memcpy(v->part_size, p->part_size, HMO_NPART); memcpy(v->pred_mode, p->pred_mode, HMO_NPART);
+  memcpy(v->tr_idx, p->tr_idx, HMO_NPART); memcpy(v->intra_dir[0], p->intra_dir[0], HMO_NPART); memcpy(v->intra_dir[1], p->intra_dir[1], HMO_NPART);
+}
+int hmo_test_mpm(HmoEnc *e, int ctu, int part, int *preds)
+{
+  e->cur_ctu = ctu;
+  view_from_pic(e, ctu, e->temp[0]);
+  return intra_dir_predictor(e, e->temp[0], part, preds);
+}
+int hmo_test_ctx_split(HmoEnc *e, int ctu, int part, int depth)
+{
+  e->cur_ctu = ctu;
+  HmoCU *cu = e->temp[0];
+  view_from_pic(e, ctu, cu);
+  int z = part, lx = cu->x + part_x(z), ly = cu->y + part_y(z), ctx = 0;
+  if (left_ctu_ok(e, lx, ly)) ctx += nb_depth(e, cu, lx - 1, ly) > depth;
+  if (above_ctu_ok(e, lx, ly)) ctx += nb_depth(e, cu, lx, ly - 1) > depth;
+  return ctx;
+}
+/* prediction of the block at component position (px,py), size 1<<log2; returns 2 if the filtered
+ * reference was used.  ref_unf/ref_filt: 4N+1 samples in walk order. */
+int hmo_test_intra(HmoEnc *e, int comp, int px, int py, int log2, int mode, uint8_t *pred, int16_t *ref_unf, int16_t *ref_filt)
+{
+  const int N = 1 << log2;
+  uint8_t ref[4 * 64 + 1], reff[4 * 64 + 1];
+  { int sh = comp ? 1 : 0; e->cur_ctu = ((py << sh) >> 6) * e->w_ctu + ((px << sh) >> 6); }
+  hmo_build_ref(e, comp, px, py, log2, 0, ref);
+  int filt = hmo_use_filtered_ref(mode, log2, comp == 0);
+  memset(reff, 0, sizeof(reff));
+  if (filt) hmo_filter_ref(ref, reff, N, comp == 0 && e->p.strong_smoothing);
+  hmo_intra_pred(filt ? reff : ref, 0, log2, mode, comp == 0, pred, N);
+  for (int i = 0; i <= 4 * N; i++) { ref_unf[i] = ref[i]; ref_filt[i] = filt ? reff[i] : 0; }
+  return filt ? 2 : 1;
+}
+/* forward transform (DST for 4x4 luma, or transform skip) + RDOQ (+ sign hiding) + dequant + inverse,
+ * with rate tables taken from the running coder e->goon.  Returns uiAbsSum. */
+int hmo_test_tq(HmoEnc *e, int comp, int log2, int lumaDir, int chromaDir, int trDepthRel, int tskip,
+                const int16_t *resi, int32_t *coef, int16_t *resi_out)
+{
+  const int N = 1 << log2;
+  HmoCU *cu = e->temp[0];
+  memset(cu->intra_dir[0], lumaDir, HMO_NPART); memset(cu->intra_dir[1], chromaDir, HMO_NPART);
+  HmoTU tu; memset(&tu, 0, sizeof(tu)); tu.tr_depth = trDepthRel; tu.log2 = comp ? log2 + 1 : log2;
+  int32_t tcoef[32 * 32];
+  if (tskip) for (int i = 0; i < N * N; i++) tcoef[i] = (int32_t)resi[i] << (15 - 8 - log2);
+  else hmo_fwd_transform(resi, N, tcoef, log2, comp == 0 && log2 == 2);
+  int absSum = hmo_rdoq(e, cu, &tu, comp, tcoef, coef, log2, 0, tskip);
+  if (absSum > 0) {
+    int32_t dq[32 * 32];
+    hmo_dequant(coef, dq, N * N, log2, comp ? e->p.qp_c : e->p.qp);
+    if (tskip) { int s = 15 - 8 - log2; for (int i = 0; i < N * N; i++) resi_out[i] = (int16_t)((dq[i] + (1 << (s - 1))) >> s); }
+    else hmo_inv_transform(dq, resi_out, N, log2, comp == 0 && log2 == 2);
+  } else { memset(coef, 0, sizeof(int32_t) * (size_t)(N * N)); memset(resi_out, 0, sizeof(int16_t) * (size_t)(N * N)); }
+  return absSum;
+}
+void hmo_test_code_coeff(HmoEnc *e, int comp, int log2, int lumaDir, int chromaDir, int tskip, const int32_t *coef)
+{
+  HmoCU *cu = e->temp[0];
+  memset(cu->intra_dir[0], lumaDir, HMO_NPART); memset(cu->intra_dir[1], chromaDir, HMO_NPART);
+  memset(cu->tskip[comp], tskip, HMO_NPART);
+  hmo_code_coeff_nxn(e, cu, coef, log2, comp, 0);
+}
+void hmo_test_cabac_get(const HmoEnc *e, uint8_t *ctx, uint64_t *frac) { memcpy(ctx, e->goon.ctx, HMO_NCTX); *frac = e->goon.frac; }
+void hmo_test_reset_bits(HmoEnc *e) { hmo_reset_bits(e); }
+double hmo_test_rd_cost(const HmoEnc *e, uint32_t bits, uint32_t dist) { return calc_rd_cost(e, bits, dist); }
+uint32_t hmo_test_chroma_dist(const HmoEnc *e, uint32_t sse) { return (uint32_t)(e->p.chroma_weight * (double)sse); }

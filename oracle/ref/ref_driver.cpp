@@ -1,0 +1,286 @@
+/*
+ * ref_driver.cpp -- ORACLE / test infrastructure.  A thin C driver over the REFERENCE's own leaf
+ * classes (compiled in place from /root/reference by build_ref.sh).  It contains no restated
+ * algorithm: every number it returns is produced by the reference's code.  Used by
+ * oracle/ref/make_golden.py to generate tests/golden/*.npz, and (when oracle/_ref exists) by the
+ * tests directly.
+ */
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <iomanip>
+#include <vector>
+#include <list>
+#include <map>
+#include <set>
+#include <deque>
+#include <string>
+#include <algorithm>
+#include <limits>
+#include <memory>
+#include <functional>
+#include <utility>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <cassert>
+#include <cstdio>
+#include <stdint.h>
+#define private public
+#define protected public
+#include "TLibCommon/CommonDef.h"
+#include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComSlice.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComTU.h"
+#include "TLibCommon/TComPrediction.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComRdCost.h"
+#include "TLibCommon/TComBitCounter.h"
+#include "TLibEncoder/TEncSbac.h"
+#include "TLibEncoder/TEncEntropy.h"
+#include "TLibEncoder/TEncBinCoderCABACCounter.h"
+#undef private
+#undef protected
+#include <math.h>
+#include <string.h>
+
+Void xTrMxN(Int bitDepth, TCoeff *block, TCoeff *coeff, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
+Void xITrMxN(Int bitDepth, TCoeff *coeff, TCoeff *block, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
+
+static TComSPS g_sps; static TComPPS g_pps; static TComPic *g_pic = 0; static TComSlice *g_slice = 0;
+static TComPrediction *g_pred = 0; static TComTrQuant *g_trq = 0; static TComRdCost *g_rd = 0;
+static TEncSbac *g_sbac = 0; static TEncBinCABACCounter *g_bin = 0; static TEncEntropy *g_ent = 0; static TComBitCounter *g_bits = 0;
+static int g_qp = 32;
+
+extern "C" {
+
+int ref_setup(int width, int height, int qp)
+{
+  g_qp = qp;
+  g_uiMaxCUWidth = 64; g_uiMaxCUHeight = 64; g_uiMaxCUDepth = 4; g_uiAddCUDepth = 1;
+  g_bitDepth[0] = g_bitDepth[1] = 8; g_maxTrDynamicRange[0] = g_maxTrDynamicRange[1] = 15;
+  initROM();
+  ContextModel::buildNextStateTable();               /* TEncTop::TEncTop(), TEncTop.cpp */
+  UInt *piTmp = &g_auiZscanToRaster[0];
+  initZscanToRaster(5, 1, 0, piTmp);           /* m_uhTotalDepth = g_uiMaxCUDepth + 1, TEncCu.cpp:167,206 */
+  initRasterToZscan(64, 64, 5);
+  initRasterToPelXY(64, 64, 5);
+  g_sps.setChromaFormatIdc(CHROMA_420);
+  g_sps.setPicWidthInLumaSamples(width); g_sps.setPicHeightInLumaSamples(height);
+  g_sps.setMaxCUWidth(64); g_sps.setMaxCUHeight(64); g_sps.setMaxCUDepth(4);
+  g_sps.setLog2MinCodingBlockSize(3); g_sps.setLog2DiffMaxMinCodingBlockSize(3);
+  g_sps.setQuadtreeTULog2MaxSize(5); g_sps.setQuadtreeTULog2MinSize(2);
+  g_sps.setQuadtreeTUMaxDepthInter(3); g_sps.setQuadtreeTUMaxDepthIntra(3);
+  g_sps.setMaxTrSize(32); g_sps.setUsePCM(false); g_sps.setUseAMP(true);
+  g_sps.setBitDepth(CHANNEL_TYPE_LUMA, 8); g_sps.setBitDepth(CHANNEL_TYPE_CHROMA, 8);
+  g_sps.setQpBDOffset(CHANNEL_TYPE_LUMA, 0); g_sps.setQpBDOffset(CHANNEL_TYPE_CHROMA, 0);
+  g_sps.setUseStrongIntraSmoothing(true);
+  g_pps.setUseTransformSkip(true); g_pps.setTransformSkipLog2MaxSize(2); g_pps.setSignHideFlag(true);
+  g_pps.setUseDQP(false); g_pps.setConstrainedIntraPred(false);
+  g_pic = new TComPic();
+  g_pic->create(g_sps, g_pps, 64, 64, 4, false);
+  g_slice = g_pic->getSlice(0);
+  g_slice->setSPS(&g_pic->getPicSym()->getSPS()); g_slice->setPPS(&g_pic->getPicSym()->getPPS());
+  g_slice->setSliceType(I_SLICE); g_slice->setSliceQp(qp); g_slice->setPic(g_pic);
+  g_slice->setSliceCurStartCtuTsAddr(0); g_slice->setSliceCurEndCtuTsAddr(g_pic->getNumberOfCtusInFrame());
+  g_slice->setSliceSegmentCurStartCtuTsAddr(0); g_slice->setSliceSegmentCurEndCtuTsAddr(g_pic->getNumberOfCtusInFrame());
+  for (UInt a = 0; a < g_pic->getNumberOfCtusInFrame(); a++) {
+    TComDataCU *c = g_pic->getCtu(a);
+    c->initCtu(g_pic, a);
+    c->setPredModeSubParts(MODE_INTRA, 0, 0); c->setPartSizeSubParts(SIZE_2Nx2N, 0, 0);
+  }
+  g_pred = new TComPrediction(); g_pred->initTempBuff(CHROMA_420);
+  g_rd = new TComRdCost(); g_rd->init();
+  g_trq = new TComTrQuant(); g_trq->init(32, true, true, true, true, false);
+  g_trq->setFlatScalingList(CHROMA_420); g_trq->setUseScalingList(false);
+  /* slice lambda as TEncSlice::initEncSlice / setUpLambda do for an I slice */
+  const double lambda = 0.57 * pow(2.0, ((double)qp - 12) / 3.0);
+  const int qpc = (int)g_aucChromaScale[CHROMA_420][qp];
+  const double w = pow(2.0, (qp - qpc) / 3.0);
+  g_rd->setLambda(lambda);
+  g_rd->setDistortionWeight(COMPONENT_Cb, w); g_rd->setDistortionWeight(COMPONENT_Cr, w);
+  double lambdas[3] = { lambda, lambda / w, lambda / w };
+  g_trq->setLambdas(lambdas);
+  g_bits = new TComBitCounter(); g_bin = new TEncBinCABACCounter(); g_sbac = new TEncSbac(); g_ent = new TEncEntropy();
+  g_sbac->init(g_bin);
+  g_ent->setEntropyCoder(g_sbac, g_slice);
+  g_ent->setBitstream(g_bits);
+  g_ent->resetEntropy();
+  g_bin->setBinCountingEnableFlag(true);
+  return (int)g_pic->getNumberOfCtusInFrame();
+}
+
+/* ---- tables -------------------------------------------------------------------------- */
+void ref_zscan_to_raster(int *out) { for (int i = 0; i < 256; i++) out[i] = (int)g_auiZscanToRaster[i]; }
+void ref_scan(int grouped, int type, int log2w, int *out) { const UInt *s = g_scanOrder[grouped ? SCAN_GROUPED_4x4 : SCAN_UNGROUPED][type][log2w][log2w]; for (int i = 0; i < (1 << (2 * log2w)); i++) out[i] = (int)s[i]; }
+void ref_dct(int log2, int *out)
+{
+  const int n = 1 << log2;
+  for (int k = 0; k < n; k++) for (int j = 0; j < n; j++)
+    out[k * n + j] = log2 == 2 ? g_aiT4[TRANSFORM_FORWARD][k][j] : log2 == 3 ? g_aiT8[TRANSFORM_FORWARD][k][j] : log2 == 4 ? g_aiT16[TRANSFORM_FORWARD][k][j] : g_aiT32[TRANSFORM_FORWARD][k][j];
+}
+int ref_chroma_qp(int qp) { return g_aucChromaScale[CHROMA_420][qp]; }
+int ref_entropy_bits(int stateXorBin) { return ContextModel::m_entropyBits[stateXorBin]; }
+int ref_next_state(int state, int bin) { return ContextModel::m_nextState[state][bin]; }
+
+/* ---- transforms / distortion ----------------------------------------------------------- */
+void ref_fwd(const short *resi, int log2, int useDst, int *coef)
+{
+  const int n = 1 << log2; TCoeff blk[1024], out[1024];
+  for (int i = 0; i < n * n; i++) blk[i] = resi[i];
+  xTrMxN(8, blk, out, n, n, useDst != 0, 15);
+  for (int i = 0; i < n * n; i++) coef[i] = out[i];
+}
+void ref_inv(const int *coef, int log2, int useDst, short *resi)
+{
+  const int n = 1 << log2; TCoeff in[1024], out[1024];
+  for (int i = 0; i < n * n; i++) in[i] = coef[i];
+  xITrMxN(8, in, out, n, n, useDst != 0, 15);
+  for (int i = 0; i < n * n; i++) resi[i] = (short)out[i];
+}
+static void to_pel(const unsigned char *s, Pel *d, int n) { for (int i = 0; i < n; i++) d[i] = s[i]; }
+unsigned ref_satd(const unsigned char *org, const unsigned char *cur, int w, int h)
+{
+  static Pel a[4096], b[4096]; to_pel(org, a, w * h); to_pel(cur, b, w * h);
+  DistParam dp; g_rd->setDistParam(dp, 8, a, w, b, w, w, h, true); dp.bApplyWeight = false;
+  return dp.DistFunc(&dp);
+}
+unsigned ref_sse(const unsigned char *org, const unsigned char *cur, int w, int h, int comp)
+{
+  static Pel a[4096], b[4096]; to_pel(org, a, w * h); to_pel(cur, b, w * h);
+  return g_rd->getDistPart(8, b, w, a, w, w, h, ComponentID(comp));
+}
+double ref_rd_cost(unsigned bits, unsigned dist) { return g_rd->calcRdCost(bits, dist); }
+double ref_lambda(int which) { return which == 0 ? g_rd->getLambda() : which == 1 ? g_rd->getSqrtLambda() : g_rd->m_distortionWeight[1]; }
+
+/* ---- picture state --------------------------------------------------------------------- */
+void ref_set_rec(int comp, const unsigned char *plane)
+{
+  TComPicYuv *r = g_pic->getPicYuvRec(); const ComponentID c = ComponentID(comp);
+  Pel *p = r->getAddr(c); const int s = r->getStride(c), w = r->getWidth(c), h = r->getHeight(c);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) p[y * s + x] = plane[y * w + x];
+}
+/* field: 0 depth, 1 part_size, 2 pred_mode, 3 luma dir, 4 chroma dir, 5 tr_idx, 6..8 tskip, 9..11 cbf, 12 width/height from depth */
+void ref_set_ctu_field(int ctu, int field, const unsigned char *v)
+{
+  TComDataCU *c = g_pic->getCtu(ctu);
+  for (int i = 0; i < 256; i++) {
+    switch (field) {
+      case 0: c->getDepth()[i] = v[i]; c->getWidth()[i] = c->getHeight()[i] = (UChar)(64 >> v[i]); break;
+      case 1: c->getPartitionSize()[i] = (Char)v[i]; break;
+      case 2: c->getPredictionMode()[i] = (Char)v[i]; break;
+      case 3: c->getIntraDir(CHANNEL_TYPE_LUMA)[i] = v[i]; break;
+      case 4: c->getIntraDir(CHANNEL_TYPE_CHROMA)[i] = v[i]; break;
+      case 5: c->getTransformIdx()[i] = v[i]; break;
+      case 6: case 7: case 8: c->getTransformSkip(ComponentID(field - 6))[i] = v[i]; break;
+      case 9: case 10: case 11: c->getCbf(ComponentID(field - 9))[i] = v[i]; break;
+    }
+  }
+}
+
+/* descend a TU tree: root = the CU at (zidx, depth) of CTU `ctu`; path[k] = child index at level k */
+struct TuChain { TComTURecurse *lv[5]; int n; };
+static TComTU *make_tu(TuChain &t, TComDataCU *cu, int zidx, int depth, int nsplit, const int *path, bool processLast)
+{
+  t.n = 0;
+  t.lv[t.n++] = new TComTURecurse(cu, zidx, depth);
+  for (int k = 0; k < nsplit; k++) {
+    TComTURecurse *c = new TComTURecurse(*t.lv[t.n - 1], processLast);
+    for (int i = 0; i < path[k]; i++) c->nextSection(*t.lv[t.n - 1]);
+    t.lv[t.n++] = c;
+  }
+  return t.lv[t.n - 1];
+}
+static void free_tu(TuChain &t) { for (int i = t.n - 1; i >= 0; i--) delete t.lv[i]; }
+
+/* intra prediction of one block exactly as xIntraCodingTUBlock does it (TEncSearch.cpp:1166-1171) */
+int ref_intra(int ctu, int zidx, int depth, int nsplit, const int *path, int comp, int mode, unsigned char *pred, short *ref_unf, short *ref_filt)
+{
+  TComDataCU *cu = g_pic->getCtu(ctu); TuChain tc;
+  cu->setDepthSubParts(depth, zidx); cu->setSizeSubParts(64 >> depth, 64 >> depth, zidx, depth);
+  TComTU *tu = make_tu(tc, cu, zidx, depth, nsplit, path, false);
+  const ComponentID c = ComponentID(comp);
+  if (!tu->ProcessComponentSection(c)) { free_tu(tc); return 0; }
+  const int w = tu->getRect(c).width, h = tu->getRect(c).height;
+  Bool above = false, left = false;
+  const Bool filt = TComPrediction::filteringIntraReferenceSamples(c, mode, w, h, CHROMA_420, false);
+  g_pred->initAdiPatternChType(*tu, above, left, c, filt);
+  static Pel dst[64 * 64];
+  g_pred->predIntraAng(c, mode, 0, 0, dst, w, *tu, above, left, filt);
+  for (int i = 0; i < w * h; i++) pred[i] = (unsigned char)dst[i];
+  const int sw = 2 * w + 1;
+  const Pel *u = g_pred->getPredictorPtr(c, false), *f = g_pred->getPredictorPtr(c, true);
+  /* linear walk: bottom-left ... corner ... top-right */
+  for (int i = 0; i < 2 * h; i++) { ref_unf[i] = u[(2 * h - i) * sw]; ref_filt[i] = filt ? f[(2 * h - i) * sw] : 0; }
+  for (int i = 0; i <= 2 * w; i++) { ref_unf[2 * h + i] = u[i]; ref_filt[2 * h + i] = filt ? f[i] : 0; }
+  free_tu(tc);
+  return filt ? 2 : 1;
+}
+
+int ref_mpm(int ctu, int part, int *preds)
+{
+  Int mode = -1; Int p[3] = { -1, -1, -1 };
+  g_pic->getCtu(ctu)->getIntraDirPredictor(part, p, COMPONENT_Y, &mode);
+  preds[0] = p[0]; preds[1] = p[1]; preds[2] = p[2];
+  return mode;
+}
+int ref_ctx_split(int ctu, int part, int depth) { return g_pic->getCtu(ctu)->getCtxSplitFlag(part, depth); }
+
+/* ---- entropy coder state ----------------------------------------------------------------- */
+void ref_cabac_reset(void) { g_ent->resetEntropy(); g_ent->resetBits(); }
+void ref_cabac_reset_bits(void) { g_ent->resetBits(); }
+unsigned long long ref_cabac_frac(void) { return g_bin->m_fracBits; }
+unsigned ref_cabac_bits(void) { return g_ent->getNumberOfWrittenBits(); }
+/* HM context order (TEncSbac.cpp:56-96); returns the number of models */
+int ref_cabac_states(unsigned char *out) { for (int i = 0; i < g_sbac->m_numContextModels; i++) out[i] = g_sbac->m_contextModels[i].m_ucState; return g_sbac->m_numContextModels; }
+
+/* transformNxN (DCT/DST/TS + RDOQ + sign hiding) then invTransformNxN on one TU; CU fields are set
+ * like the search would have set them.  Rate tables come from the current coder state. */
+int ref_tq(int ctu, int zidx, int depth, int nsplit, const int *path, int comp, int partSize, int lumaDir, int chromaDir,
+           int tskip, const short *resi, int *coef, short *resi_out)
+{
+  TComDataCU *cu = g_pic->getCtu(ctu); TuChain tc;
+  const ComponentID c = ComponentID(comp);
+  cu->setPredModeSubParts(MODE_INTRA, zidx, depth); cu->setPartSizeSubParts(PartSize(partSize), zidx, depth);
+  cu->setDepthSubParts(depth, zidx); cu->setSizeSubParts(64 >> depth, 64 >> depth, zidx, depth);
+  cu->setIntraDirSubParts(CHANNEL_TYPE_LUMA, lumaDir, zidx, depth); cu->setIntraDirSubParts(CHANNEL_TYPE_CHROMA, chromaDir, zidx, depth);
+  cu->setQPSubParts(g_qp, zidx, depth);
+  TComTU *tu = make_tu(tc, cu, zidx, depth, nsplit, path, false);
+  if (!tu->ProcessComponentSection(c)) { free_tu(tc); return -1; }
+  const int w = tu->getRect(c).width, h = tu->getRect(c).height;
+  cu->setTransformSkipPartRange(tskip, c, tu->GetAbsPartIdxTU(c), tu->GetAbsPartIdxNumParts(c));
+  static Pel r[32 * 32]; static TCoeff q[32 * 32], arl[32 * 32];
+  for (int i = 0; i < w * h; i++) r[i] = resi[i];
+  g_ent->estimateBit(g_trq->m_pcEstBitsSbac, w, h, toChannelType(c));
+  const QpParam cQP(*cu, c);
+  g_trq->selectLambda(c);
+  TCoeff absSum = 0;
+  g_trq->transformNxN(*tu, c, r, w, q, arl, absSum, cQP);
+  for (int i = 0; i < w * h; i++) coef[i] = q[i];
+  if (absSum > 0) g_trq->invTransformNxN(*tu, c, r, w, q, cQP);
+  else memset(r, 0, sizeof(Pel) * w * h);
+  for (int i = 0; i < w * h; i++) resi_out[i] = r[i];
+  free_tu(tc);
+  return (int)absSum;
+}
+
+/* codeCoeffNxN bit count on the running coder (TEncEntropy::encodeCoeffNxN needs cbf != 0) */
+void ref_code_coeff(int ctu, int zidx, int depth, int nsplit, const int *path, int comp, int partSize, int lumaDir, int chromaDir, int tskip, const int *coef)
+{
+  TComDataCU *cu = g_pic->getCtu(ctu); TuChain tc;
+  const ComponentID c = ComponentID(comp);
+  cu->setPredModeSubParts(MODE_INTRA, zidx, depth); cu->setPartSizeSubParts(PartSize(partSize), zidx, depth);
+  cu->setDepthSubParts(depth, zidx); cu->setSizeSubParts(64 >> depth, 64 >> depth, zidx, depth);
+  cu->setIntraDirSubParts(CHANNEL_TYPE_LUMA, lumaDir, zidx, depth); cu->setIntraDirSubParts(CHANNEL_TYPE_CHROMA, chromaDir, zidx, depth);
+  TComTU *tu = make_tu(tc, cu, zidx, depth, nsplit, path, false);
+  const int w = tu->getRect(c).width, h = tu->getRect(c).height;
+  cu->setTransformSkipPartRange(tskip, c, tu->GetAbsPartIdxTU(c), tu->GetAbsPartIdxNumParts(c));
+  static TCoeff q[32 * 32];
+  for (int i = 0; i < w * h; i++) q[i] = coef[i];
+  g_sbac->codeCoeffNxN(*tu, q, c);
+  free_tu(tc);
+}
+
+} /* extern "C" */
