@@ -94,14 +94,15 @@ def main():
     # inputs resident in HBM before timing; every chain gets its own reconstruction plane set,
     # the 4 QP chains of a frame share its source planes
     out_bytes = pkg.engine.CTU_OUT_BYTES * total_ctus_chain
-    frames, keep = [], []
-    for f in range(args.frames):
-        fr = gen_textured_gpu(torch, dev, W, H, seed=7 + f + 1000 * rank)
-        frames.append(fr)
-        for qi, qp in enumerate(qps):
-            rec = [torch.zeros_like(p) for p in fr]
-            out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
-            eng.init_chain(f * len(qps) + qi, fr, qp=qp, rec=rec, out=out)
+    frames, cache = [], {}
+    for ci, (seed, qp) in enumerate(pkg.sharding.chains_for_rank(args.frames, qps, rank)):
+        if seed not in cache:
+            cache[seed] = gen_textured_gpu(torch, dev, W, H, seed=seed)
+            frames.append(cache[seed])
+        fr = cache[seed]
+        rec = [torch.zeros_like(p) for p in fr]
+        out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+        eng.init_chain(ci, fr, qp=qp, rec=rec, out=out)
     torch.cuda.synchronize()
 
     def step():
@@ -121,11 +122,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = pkg.sharding.reduce_step_time(dist, time.perf_counter() - t0, dev)
     kernel_ms, launches = eng.kernel_ms()
 
     ctus_per_step_gpu = n_chains * args.ctus_per_step

@@ -6,5 +6,5 @@ Layout:
   engine.py              ctypes binding + `TEncCu`-shaped host class
   synth.py               synthetic YUV generators
 """
-from . import synth  # noqa: F401
+from . import sharding, synth  # noqa: F401
 from .engine import CuEngine, FrameParams, FcuError, lib_path, load_lib  # noqa: F401

@@ -1,0 +1,18 @@
+"""Chain sharding for multi-GPU runs: frames (x QPs) are independent chains, so every rank owns a
+disjoint set and no collective touches the data path.  Weak scaling: a rank's share
+does not depend on the world size."""
+
+
+def chains_for_rank(frames_per_gpu, qps, rank):
+    """[(frame_seed, qp)] of one rank; seeds are globally unique so ranks never duplicate content."""
+    return [(7 + f + 1000 * rank, qp) for f in range(frames_per_gpu) for qp in qps]
+
+
+def reduce_step_time(dist, local_seconds, device=None):
+    """Slowest rank defines the step time (MAX all-reduce); returns local_seconds when single-process."""
+    if dist is None:
+        return local_seconds
+    import torch
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
