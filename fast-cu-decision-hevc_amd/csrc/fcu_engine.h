@@ -43,6 +43,14 @@
 #define FCU_FLOOR(x) floor(x)
 #endif
 #define FCU_SERIAL FCU_FOR_LANES if (lane == 0)
+/* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
+#if defined(FCU_PROFILE) && !defined(FCU_EMU)
+#define FCU_TIC(v) const long long v = clock64()
+#define FCU_TOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#else
+#define FCU_TIC(v) do { } while (0)
+#define FCU_TOC(E_, v, idx) do { } while (0)
+#endif
 
 #include "fcu_tables.h"
 
@@ -82,6 +90,7 @@ struct Chain {
   int next_ctu;
   Cabac state;                 /* m_pppcRDSbacCoder[0][CI_CURR_BEST] between CTUs */
   unsigned long long n_tu_trials;
+  unsigned long long prof[16];
 };
 
 /* per-depth working CU (TComDataCU best/temp objects, TEncCu.cpp:163-198) */
@@ -93,6 +102,8 @@ struct CuObj {
   int16_t coef[3][CTU * CTU];
 };
 struct Yuv { uint8_t y[64 * 64], u[32 * 32], v[32 * 32]; };
+/* state of one chroma-mode trial: the mode's own reconstruction (overlay of PicYuvRec inside the CU), levels, flags */
+struct ChromaModeBuf { uint8_t u[32 * 32], v[32 * 32]; int16_t coef[2][1024]; uint8_t cbf[2][NPART], tskip[2][NPART]; };
 
 /* per-chain scratch in HBM (L2 resident working set) */
 struct Scratch {
@@ -102,11 +113,11 @@ struct Scratch {
   int16_t qt_coef[3][4][CTU * CTU];                /* m_ppcQTTempCoeff[comp][layer] */
   int16_t ts_coef[3][1024]; Yuv ts_rec; uint8_t shared_pred[3][1024];
   uint8_t tmp_tr_idx[NPART], tmp_cbf[NPART], tmp_tskip[NPART];
-  uint8_t tmpc_cbf[2][NPART], tmpc_tskip[2][NPART];
+  ChromaModeBuf cm[5];
   /* candidate pools: slot v occupies [v*N*N, (v+1)*N*N) */
   uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; int16_t p_qcoef[POOL]; uint8_t p_rec[POOL];
   /* RDOQ locals (TComTrQuant.cpp:2082-2095) */
-  double r_cc[POOL], r_cs[POOL], r_c0[POOL]; int32_t r_up[POOL], r_dn[POOL], r_sd[POOL], r_du[POOL];
+  double r_cc[POOL], r_cs[POOL], r_c0[POOL]; int32_t r_up[POOL], r_dn[POOL], r_sd[POOL], r_du[POOL]; double r_cg[MAXVC * 64];
 };
 
 /* per-chain LDS */
@@ -115,6 +126,8 @@ struct Shared {
   Cabac slot[MAXDEPTH + 2][CI_NUM];
   Cabac lane[MAXVC];
   uint8_t ref[264], reff[264];
+  uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
+  int16_t lane_abs[MAXVC][16];                      /* per-lane |level| list of the coefficient group being coded */
   int16_t diff[DIFFN];
   int32_t colsum[256];
   uint32_t sad[36];
@@ -123,7 +136,7 @@ struct Shared {
   /* PU / TU mailbox written by serial blocks */
   int rd_mode[12]; int n_rd;
   int preds[3]; int n_mpm;
-  int vc_abs[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];
+  int vc_abs[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* MAXVC >= 15: chroma uses [10..14] of vc_dist */
   int pu_best_vc, pu_best_mode; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
   int t_abs; uint32_t t_dist;
@@ -218,19 +231,20 @@ FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
   if (iabs(dir - HOR) <= 4) return 2;
   return 0;
 }
-FCU_DEV int pattern_sig_ctx(const uint8_t *cg, int cgx, int cgy, int wg)       /* TComTrQuant.cpp:2584-2609 */
+/* coefficient-group flags: bit (cgy*wg+cgx) of a 64-bit mask (<= 8x8 groups) */
+FCU_DEV int pattern_sig_ctx(uint64_t cg, int cgx, int cgy, int wg)             /* TComTrQuant.cpp:2584-2609 */
 {
   if (wg <= 1) return 0;
   int r = 0, l = 0;
-  if (cgx < wg - 1) r = cg[cgy * wg + cgx + 1] != 0;
-  if (cgy < wg - 1) l = cg[(cgy + 1) * wg + cgx] != 0;
+  if (cgx < wg - 1) r = (int)((cg >> (cgy * wg + cgx + 1)) & 1);
+  if (cgy < wg - 1) l = (int)((cg >> ((cgy + 1) * wg + cgx)) & 1);
   return r + (l << 1);
 }
-FCU_DEV int sig_cg_ctx(const uint8_t *cg, int cgx, int cgy, int wg)            /* TComTrQuant.cpp:2949-2969 */
+FCU_DEV int sig_cg_ctx(uint64_t cg, int cgx, int cgy, int wg)                  /* TComTrQuant.cpp:2949-2969 */
 {
   int r = 0, l = 0;
-  if (cgx < wg - 1) r = cg[cgy * wg + cgx + 1] != 0;
-  if (cgy < wg - 1) l = cg[(cgy + 1) * wg + cgx] != 0;
+  if (cgx < wg - 1) r = (int)((cg >> (cgy * wg + cgx + 1)) & 1);
+  if (cgy < wg - 1) l = (int)((cg >> ((cgy + 1) * wg + cgx)) & 1);
   return (r + l) != 0;
 }
 FCU_DEV int first_sig_ctx(int log2, int scan, int ch)                          /* TComChromaFormat.cpp:129-155 */
@@ -263,7 +277,7 @@ FCU_DEV void code_coef_remain(Cabac *c, uint32_t symbol, uint32_t rparam)      /
   }
 }
 /* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535 */
-FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P)
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   int numSig = 0;
@@ -273,12 +287,11 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
   const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
-  uint8_t cgflag[64];
-  for (int i = 0; i < wg * wg; i++) cgflag[i] = 0;
+  uint64_t cgflag = 0;
   int scanPosLast = -1, posLast;
   do {
     posLast = scan[++scanPosLast];
-    if (coef[posLast] != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag[wg * (py >> 2) + (px >> 2)] = 1; numSig--; }
+    if (coef[posLast] != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag |= 1ull << (wg * (py >> 2) + (px >> 2)); numSig--; }
   } while (numSig > 0);
   {
     int py = posLast >> log2, px = posLast - (py << log2);
@@ -300,17 +313,17 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
   for (int sub = lastSet; sub >= 0; sub--) {
     int numNonZero = 0; const int subPos = sub << 4;
     goRice = 0;
-    int absCoeff[16], lastNZ = -1, firstNZ = 16, escape = 0;
-    if (scanPosSig == scanPosLast) { absCoeff[0] = iabs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
+    int lastNZ = -1, firstNZ = 16, escape = 0;
+    if (scanPosSig == scanPosLast) { absCoeff[0] = (int16_t)iabs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgpos = scanCG[sub], cgy = cgpos / wg, cgx = cgpos - cgy * wg;
-    if (sub == lastSet || sub == 0) cgflag[cgpos] = 1;
-    else cab_bin(c, cgflag[cgpos] != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
-    if (cgflag[cgpos]) {
+    if (sub == lastSet || sub == 0) cgflag |= 1ull << cgpos;
+    else cab_bin(c, (int)((cgflag >> cgpos) & 1), baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
+    if ((cgflag >> cgpos) & 1) {
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       for (; scanPosSig >= subPos; scanPosSig--) {
         const int blk = scan[scanPosSig], sig = coef[blk] != 0;
         if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, baseSig + sig_ctx_inc(pattern, firstSig, blk, log2, ch));
-        if (sig) { absCoeff[numNonZero++] = iabs(coef[blk]); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
+        if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(coef[blk]); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
     if (numNonZero > 0) {
@@ -345,7 +358,7 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
 /* ======================================================================================== */
 /* RDOQ -- per-lane callable (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:2033-2573)     */
 /* ======================================================================================== */
-struct RdoqBuf { double *cc, *cs, *c0; int32_t *up, *dn, *sd, *du; };
+struct RdoqBuf { double *cc, *cs, *c0; int32_t *up, *dn, *sd, *du; double *cg; };
 
 FCU_DEV int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
 {                                                          /* xGetICRate, TComTrQuant.cpp:2807-2881 */
@@ -398,13 +411,13 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
   const double errScale = P.err_scale[ch][log2 - 2];
   double *costCoeff = rb.cc, *costSig = rb.cs, *costCoeff0 = rb.c0;
   int32_t *rateIncUp = rb.up, *rateIncDown = rb.dn, *sigRateDelta = rb.sd, *deltaU = rb.du;
-  for (int i = 0; i < n2; i++) { costCoeff[i] = 0; costSig[i] = 0; rateIncUp[i] = 0; rateIncDown[i] = 0; sigRateDelta[i] = 0; deltaU[i] = 0; }
+  /* the reference clears all seven arrays; only entries at scan positions <= the last significant one are
+   * ever read back (last-position search, group zero-out, sign hiding), and each of those is written below */
   const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
-  double costCGSig[64]; uint8_t cgflag[64];
-  for (int i = 0; i < wg * wg; i++) { costCGSig[i] = 0; cgflag[i] = 0; }
+  double *costCGSig = rb.cg; uint64_t cgflag = 0;
   int cgLastScanPos = -1; uint32_t ctxSet = 0; int c1 = 1, c2 = 0;
   double baseCost = 0, blockUncodedCost = 0;
   int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
@@ -414,6 +427,7 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
     const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
     double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
+    costCGSig[cgScanPos] = 0;
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
       const long long tmpLevel = (long long)iabs(src[blk]) * qcoef;
@@ -422,8 +436,8 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
       uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
       if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
       const double err = (double)levelDouble;
-      costCoeff0[scanPos] = err * err * errScale;
-      blockUncodedCost += costCoeff0[scanPos];
+      double c0 = err * err * errScale, cc = 0, cs = 0;
+      blockUncodedCost += c0;
       dst[blk] = (int16_t)maxAbsLevel;
       if (maxAbsLevel > 0 && lastScanPos < 0) {
         lastScanPos = scanPos;
@@ -433,23 +447,26 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
       if (lastScanPos >= 0) {
         uint32_t level;
         const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1, absCtx = CTX_ABS + (int)ctxSet + c2;
+        int sdel = 0, rup, rdn = 0;
         if (scanPos == lastScanPos)
-          level = coded_level(c, lambda, &costCoeff[scanPos], &costCoeff0[scanPos], &costSig[scanPos], levelDouble, maxAbsLevel,
+          level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
                               sigOff, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 1);
         else {
           const int ctxSig = sigOff + sig_ctx_inc(pattern, firstSig, blk, log2, ch);
-          level = coded_level(c, lambda, &costCoeff[scanPos], &costCoeff0[scanPos], &costSig[scanPos], levelDouble, maxAbsLevel,
+          level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
                               ctxSig, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 0);
-          sigRateDelta[blk] = ctx_bits(c, ctxSig, 1) - ctx_bits(c, ctxSig, 0);
+          sdel = ctx_bits(c, ctxSig, 1) - ctx_bits(c, ctxSig, 0);
         }
-        deltaU[blk] = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
         if (level > 0) {
           const int rateNow = ic_rate(c, level, oneCtx, absCtx, goRice, c1Idx, c2Idx);
-          rateIncUp[blk] = ic_rate(c, level + 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
-          rateIncDown[blk] = ic_rate(c, level - 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
-        } else rateIncUp[blk] = ctx_bits(c, oneCtx, 0);
+          rup = ic_rate(c, level + 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
+          rdn = ic_rate(c, level - 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
+        } else rup = ctx_bits(c, oneCtx, 0);
+        costCoeff[scanPos] = cc; costCoeff0[scanPos] = c0; costSig[scanPos] = cs;
+        sigRateDelta[blk] = sdel; rateIncUp[blk] = rup; rateIncDown[blk] = rdn;
+        deltaU[blk] = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
         dst[blk] = (int16_t)level;
-        baseCost += costCoeff[scanPos];
+        baseCost += cc;
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
         if (level >= 1) c1Idx++;
@@ -459,19 +476,19 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
           ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && ((scanPos - 1) >> 4) > 0) ? 2 : 0) + (c1 == 0));
           c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
         }
-      } else baseCost += costCoeff0[scanPos];
-      rdSigCost += costSig[scanPos];
-      if (posInCG == 0) rdSigCost0 = costSig[scanPos];
+      } else baseCost += c0;
+      rdSigCost += cs;
+      if (posInCG == 0) rdSigCost0 = cs;
       if (dst[blk]) {
-        cgflag[cgBlk] = 1;
-        rdCodedLevelandDist += costCoeff[scanPos] - costSig[scanPos];
-        rdUncodedDist += costCoeff0[scanPos];
+        cgflag |= 1ull << cgBlk;
+        rdCodedLevelandDist += cc - cs;
+        rdUncodedDist += c0;
         if (posInCG != 0) nnzBeforePos0++;
       }
     }
     if (cgLastScanPos >= 0) {
       if (cgScanPos) {
-        if (cgflag[cgBlk] == 0) {
+        if (((cgflag >> cgBlk) & 1) == 0) {
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
           baseCost += lambda * (double)ctx_bits(c, ctxSig, 0) - rdSigCost;
           costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
@@ -484,7 +501,7 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
           costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 1);
           costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
           if (costZeroCG < baseCost) {
-            cgflag[cgBlk] = 0; baseCost = costZeroCG;
+            cgflag &= ~(1ull << cgBlk); baseCost = costZeroCG;
             costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
             for (int posInCG = 15; posInCG >= 0; posInCG--) {
               const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
@@ -492,7 +509,7 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
             }
           }
         }
-      } else cgflag[cgBlk] = 1;
+      } else cgflag |= 1ull << cgBlk;
     }
   }
   if (lastScanPos < 0) return 0;
@@ -500,21 +517,14 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
   double bestCost; int bestLastIdxP1 = 0;
   bestCost = blockUncodedCost + lambda * (double)ctx_bits(c, cbfCtx, 0);
   baseCost += lambda * (double)ctx_bits(c, cbfCtx, 1);
-  int lastXBits[10], lastYBits[10];                         /* estLastSignificantPositionBit, TEncSbac.cpp:1863-1923 */
-  {
-    const int cc = log2 - 2, off = ch ? 0 : (cc * 3 + ((cc + 1) >> 2)), sh = ch ? cc : ((cc + 3) >> 2);
-    const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = k_group_idx[N - 1];
-    int k, bitsX = 0, bitsY = 0;
-    for (k = 0; k < gmax; k++) { lastXBits[k] = bitsX + ctx_bits(c, bx + (k >> sh), 0); bitsX += ctx_bits(c, bx + (k >> sh), 1); }
-    lastXBits[k] = bitsX;
-    for (k = 0; k < gmax; k++) { lastYBits[k] = bitsY + ctx_bits(c, by + (k >> sh), 0); bitsY += ctx_bits(c, by + (k >> sh), 1); }
-    lastYBits[k] = bitsY;
-  }
+  /* estLastSignificantPositionBit (TEncSbac.cpp:1863-1923) evaluated on demand */
+  const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
+  const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = k_group_idx[N - 1];
   int foundLast = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos];
     baseCost -= costCGSig[cgScanPos];
-    if (cgflag[cgBlk]) {
+    if ((cgflag >> cgBlk) & 1) {
       for (int posInCG = 15; posInCG >= 0; posInCG--) {
         const int scanPos = cgScanPos * 16 + posInCG;
         if (scanPos > lastScanPos) continue;
@@ -523,7 +533,12 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
           const int py = blk >> log2, px = blk - (py << log2);
           const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
           const int gx = k_group_idx[ax], gy = k_group_idx[ay];
-          double r = (double)(lastXBits[gx] + lastYBits[gy]);              /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
+          int bxs = 0, bys = 0;
+          for (int k = 0; k < gx; k++) bxs += ctx_bits(c, lbx + (k >> lsh), 1);
+          if (gx < lgmax) bxs += ctx_bits(c, lbx + (gx >> lsh), 0);
+          for (int k = 0; k < gy; k++) bys += ctx_bits(c, lby + (k >> lsh), 1);
+          if (gy < lgmax) bys += ctx_bits(c, lby + (gy >> lsh), 0);
+          double r = (double)(bxs + bys);                                  /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
           if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
           if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
           const double costLast = lambda * r;
@@ -829,7 +844,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, 
           const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
-          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p);
+          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, E.S->lane_abs[0]);
         }
         sp--; continue;
       }
@@ -887,7 +902,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(const Env &E, Cabac *c, const CuObj *
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
           const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
-          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p);
+          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, E.S->lane_abs[0]);
         }
         sp--; continue;
       }
@@ -1020,10 +1035,12 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int co
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
     if (lane == 0) {
-      RdoqBuf rb = { G->r_cc, G->r_cs, G->r_c0, G->r_up, G->r_dn, G->r_sd, G->r_du };
+      FCU_TIC(t8_);
+      RdoqBuf rb = { G->r_cc, G->r_cs, G->r_c0, G->r_up, G->r_dn, G->r_sd, G->r_du, G->r_cg };
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
       S->t_abs = rdoq(cab, G->p_tcoef, G->p_qcoef, log2, comp, coef_scan_idx(mode, log2, comp), cbfCtx, P, rb);
       E.C->n_tu_trials++;
+      FCU_TOC(E, t8_, 8);
     }
   }
   const int absSum = S->t_abs;
@@ -1081,7 +1098,7 @@ FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env &E, const CuObj *cu, co
 /* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to S->q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst, int reuseVc = -1)
 {
   Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
@@ -1120,11 +1137,27 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
     } else {
       if (checkSplit) FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = 0; }
-      tu_trial(E, cu, tu, 0, &S->goon, 0);
-      singleDist = S->t_dist;
-      if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
-      FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
-      singleCost = rd_cost(P, S->vc_bits[0], singleDist);
+      if (reuseVc >= 0) {
+        /* the un-split trial of the re-run (TEncSearch.cpp:2518-2586) repeats the first-pass trial of the same mode
+         * from the same snapshot: take its levels, reconstruction, distortion, bits and coder state instead of
+         * recomputing them (the candidate pools still hold them) */
+        const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = S->vc_abs[bv] > 0;
+        FCU_FOR_LANES {
+          for (int i = lane; i < n2; i += 64) {
+            G->qt_coef[0][layer][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
+            G->qt_rec[layer].y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
+          }
+          for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
+          cab_copy(&S->goon, &S->lane[bv], lane);
+        }
+        singleDist = S->vc_dist[bv]; singleCbf = (uint32_t)cbf; singleCost = S->vc_cost[bv];
+      } else {
+        tu_trial(E, cu, tu, 0, &S->goon, 0);
+        singleDist = S->t_dist;
+        if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
+        FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
+        singleCost = rd_cost(P, S->vc_bits[0], singleDist);
+      }
     }
   }
   if (checkSplit) {
@@ -1300,16 +1333,18 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
       G->p_tcoef[i] = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
     }
   }
+  FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
     if (lane < nvc) {
       const int mode = S->rd_mode[lane / tsv];
-      RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2 };
+      RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
       S->vc_abs[lane] = rdoq(&S->slot[d][CI_CURR_BEST], G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
       S->vc_dist[lane] = 0;
     }
     if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
   }
+  FCU_TOC(E, t2_, 2);
   FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = S->vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp) : 0; } }
   FCU_FOR_LANES {
     for (int i = lane; i < nvc * n2; i += 64) {
@@ -1329,6 +1364,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
       FCU_ATOMIC_ADD(&S->vc_dist[v], (uint32_t)(e * e));
     }
   }
+  FCU_TIC(t3_);
   FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
     if (lane < nvc) {
       const int cnd = lane / tsv, ts = lane % tsv, mode = S->rd_mode[cnd], cbf = S->vc_abs[lane] > 0;
@@ -1343,13 +1379,14 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
         if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
           cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P);
+        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P, S->lane_abs[lane]);
         S->vc_bits[lane] = cab_bits(c);
         cost = rd_cost(P, S->vc_bits[lane], S->vc_dist[lane]);
       }
       S->vc_cost[lane] = cost;
     }
   }
+  FCU_TOC(E, t3_, 3);
   FCU_SERIAL {                                               /* strict '<', earlier candidate wins ties */
     double best = FCU_MAX_DOUBLE; int bv = 0;
     for (int cnd = 0; cnd < nc; cnd++) {
@@ -1386,9 +1423,9 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
   for (int pu = 0; pu < numPU; pu++) {
     TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
-    rmd(E, cu, tu);
+    { FCU_TIC(t_); rmd(E, cu, tu); FCU_TOC(E, t_, 0); }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
-    if (singleTU) pu_first_pass_batched(E, cu, tu);
+    if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(E, cu, tu); FCU_TOC(E, t_, 1); }
     else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
       FCU_SERIAL { S->pu_best_cost = FCU_MAX_DOUBLE; S->pu_best_mode = 0; S->pu_best_dist = 0; }
       const int nc = S->n_rd;
@@ -1409,7 +1446,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
     if (log2 > min_tu_log2_in_cu(d, partSize)) {
       const int orgMode = S->pu_best_mode;
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
-      recur_luma_qt<0>(E, cu, tu, 0);
+      { FCU_TIC(t_); recur_luma_qt<0>(E, cu, tu, 0, singleTU ? S->pu_best_vc : -1); FCU_TOC(E, t_, 4); }
       if (S->q_cost[0] < S->pu_best_cost) {
         FCU_SERIAL { S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
         set_intra_result_luma_qt(E, cu, tu, recoT);
@@ -1440,78 +1477,200 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
 }
 
 /* ======================================================================================== */
-/* chroma: xRecurIntraChromaCodingQT / estIntraPredChromaQT, TEncSearch.cpp:1916-2120,2661-2810 */
+/* chroma search, the five modes side by side (estIntraPredChromaQT + xRecurIntraChroma-      */
+/* CodingQT, TEncSearch.cpp:1916-2120,2661-2810).  Every mode restarts from [d][CURR_BEST]    */
+/* (:2713) and only reads its OWN reconstruction inside the CU, so the modes are independent:  */
+/* the luma TU tree is walked once, and at every chroma leaf the wave runs prediction /         */
+/* transform / reconstruction for all modes, RDOQ and bit counting one mode (x transform-skip   */
+/* variant) per lane on lane-private coders.                                                   */
 /* ======================================================================================== */
-template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_chroma_qt(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV void chroma_leaf_refs5(const Env &E, const CuObj *cu, int comp, int px, int py, int log2)
 {
-  Shared *S = E.S; const Params &P = E.C->p;
-  const int part = tu.part, trDepth = tu.tr_depth;
-  if (cu->tr_idx[part] == trDepth) {
-    if (tu.cw == 0) return;
-    const int fullDepth = cu->depth_cu + trDepth;
-    int checkTS = P.transform_skip && tu.cw <= 4;
-    if (P.ts_fast) {
-      checkTS = checkTS && (tu.log2 == 2);
-      if (checkTS) { int nb = 0; const int maxp = part + (tu.c_code_all ? 1 : 4); for (int p = part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
-    }
-    const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
-    for (int comp = 1; comp < 3; comp++) {
-      FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
-      double singleCost = FCU_MAX_DOUBLE, tmpCost = 0; int bestModeId = 0, bestTS = 0; uint32_t singleDistC = 0, singleCbfC = 0;
-      const int modesToTest = checkTS ? 2 : 1;
-      int currModeId = 0;
-      for (int tsMode = 0; tsMode < modesToTest; tsMode++) {
-        FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->tskip[comp][subPart + i] = (uint8_t)tsMode; }
-        currModeId++;
-        const int isOne = modesToTest == 1, isLast = currModeId == modesToTest;
-        tu_trial(E, cu, tu, comp, &S->goon, isOne ? 0 : (tsMode == 0 ? 1 : 2));
-        const uint32_t tmpDist = S->t_dist, tmpCbf = (cu->cbf[comp][subPart] >> trDepth) & 1;
-        if (tsMode == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
-        else if (!isOne) {
-          FCU_SERIAL { cab_reset_bits(&S->goon); enc_coeff_qt(E, &S->goon, cu, tu, comp, 0); S->vc_bits[0] = cab_bits(&S->goon); }
-          tmpCost = rd_cost(P, S->vc_bits[0], tmpDist);
+  /* reference samples of one chroma block for the five modes: outside the CU from the picture, inside from
+   * the mode's own overlay (what PicYuvRec would hold during that mode's trial, TEncSearch.cpp:1374) */
+  Shared *S = E.S; Scratch *G = E.G;
+  const int N = 1 << log2, total = 4 * N + 1, lx0 = px << 1, ly0 = py << 1;
+  const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
+  const int cx0 = cu->x >> 1, cy0 = cu->y >> 1, cs = (CTU >> cu->depth_cu) >> 1;
+  uint8_t *avail = (uint8_t *)S->colsum;
+  FCU_FOR_LANES {
+    for (int i = lane; i < total; i += 64) {
+      int a, x, y;
+      if (i < 2 * N) { y = py + 2 * N - 1 - i; x = px - 1; a = unit_available(E, lx0 - 4, (y / 2 * 2) << 1, lx0, ly0); }
+      else if (i == 2 * N) { y = py - 1; x = px - 1; a = unit_available(E, lx0 - 4, ly0 - 4, lx0, ly0); }
+      else { x = px + i - 2 * N - 1; y = py - 1; a = unit_available(E, (x / 2 * 2) << 1, ly0 - 4, lx0, ly0); }
+      avail[i] = (uint8_t)a;
+      if (a) {
+        const int inside = x >= cx0 && x < cx0 + cs && y >= cy0 && y < cy0 + cs;
+        for (int m = 0; m < 5; m++) {
+          const uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
+          S->ref5[m][i] = inside ? ov[(y - cy0) * 32 + (x - cx0)] : rec[y * stride + x];
         }
-        if (tmpCost < singleCost) {
-          singleCost = tmpCost; singleDistC = tmpDist; bestTS = tsMode; bestModeId = currModeId; singleCbfC = tmpCbf;
-          if (!isOne && !isLast) { store_intra_result_qt(E, tu, comp); FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_TEMP_BEST], &S->goon, lane); }
-        }
-        if (!isOne && !isLast) FCU_FOR_LANES cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
       }
-      if (bestModeId < modesToTest) {
-        load_intra_result_qt(E, cu, tu, comp);
-        FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->cbf[comp][subPart + i] = (uint8_t)(singleCbfC << trDepth); cab_copy(&S->goon, &S->slot[fullDepth][CI_TEMP_BEST], lane); }
-      }
-      FCU_FOR_LANES { for (int i = lane; i < nPartsC; i += 64) cu->tskip[comp][subPart + i] = (uint8_t)bestTS; if (lane == 0) S->c_dist += singleDistC; }
-    }
-  } else {
-    if constexpr (LEVEL < 3) {
-      uint32_t splitCbf[3] = { 0, 0, 0 };
-      for (int i = 0; i < 4; i++) {
-        TU c; tu_child(c, tu, i, 0);
-        recur_chroma_qt<LEVEL + 1>(E, cu, c);
-        for (int comp = 1; comp < 3; comp++) splitCbf[comp] |= (cu->cbf[comp][c.part] >> c.tr_depth) & 1;
-      }
-      FCU_FOR_LANES { for (int comp = 1; comp < 3; comp++) if (splitCbf[comp]) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[comp][part + o] |= (uint8_t)(1 << trDepth); }
     }
   }
+  FCU_FOR_LANES {
+    for (int i = lane; i < total; i += 64) {
+      if (!avail[i]) {
+        int j = i - 1;
+        while (j >= 0 && !avail[j]) j--;
+        if (j < 0) { j = i + 1; while (j < total && !avail[j]) j++; }
+        for (int m = 0; m < 5; m++) S->ref5b[m][i] = (j < total) ? S->ref5[m][j] : 128;
+      }
+    }
+  }
+  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) for (int m = 0; m < 5; m++) S->ref5[m][i] = S->ref5b[m][i]; }
+  FCU_FOR_LANES { if (lane < 5) { int sum = 0; for (int i = 0; i < N; i++) sum += S->ref5[lane][2 * N + 1 + i] + S->ref5[lane][2 * N - 1 - i]; S->dc5[lane] = (sum + N) >> (log2 + 1); } }
 }
-FCU_DEV FCU_NOINLINE void set_intra_result_chroma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)   /* TEncSearch.cpp:2126-2175 */
+
+/* xGetIntraBitsQT(rTu, false, true) for mode slot m from the lane-private coder c (serial, one lane) */
+FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env &E, Cabac *c, const CuObj *cu, int m, int mode, int16_t *absbuf)
 {
-  Scratch *G = E.G;
+  const ChromaModeBuf *B = &E.G->cm[m];
+  cab_reset_bits(c);
+  code_intra_dir_chroma(c, mode);
+  TU st[4]; int ci[4];
+  for (int pass = 0; pass < 3; pass++) {                      /* 0: subdiv/cbf walk, 1: Cb coefficients, 2: Cr coefficients */
+    int sp = 0; tu_root(st[0], cu->depth_cu); ci[0] = -1;
+    while (sp >= 0) {
+      const TU &tu = st[sp];
+      if (ci[sp] < 0) {
+        const int subdiv = cu->tr_idx[tu.part] > tu.tr_depth;
+        if (pass == 0) {
+          for (int k = 0; k < 2; k++)
+            if (tu.c_code_all && (tu.tr_depth == 0 || ((B->cbf[k][tu.part] >> (tu.tr_depth - 1)) & 1))) {
+              const int lowest = tu.tr_depth + ((subdiv && !(tu.cw >= 8)) ? 1 : 0);
+              cab_bin(c, (B->cbf[k][tu_part_c(tu)] >> lowest) & 1, CTX_CBF_CHROMA + tu.tr_depth);
+            }
+        } else if (!subdiv) {
+          const int k = pass - 1;
+          if (tu.cw != 0 && ((B->cbf[k][tu.part] >> tu.tr_depth) & 1)) {
+            const int log2 = ilog2(tu.cw), pc = tu_part_c(tu);
+            const int fmode = mode == DM_CHROMA ? cu->intra_dir[0][pc & ~3] : mode;
+            code_coeff_nxn(c, B->coef[k] + tu.off_c, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
+          }
+        }
+        if (!subdiv) { sp--; continue; }
+        ci[sp] = 0;
+      }
+      if (ci[sp] >= 4) { sp--; continue; }
+      { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+    }
+  }
+  return cab_bits(c);
+}
+
+FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
+{
+  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, n = cu->nparts, cs = (CTU >> d) >> 1;
+  int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
+  { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
+  FCU_FOR_LANES {
+    if (lane < 5) { cab_copy1(&S->lane[lane], &S->slot[d][CI_CURR_BEST]); S->cm_dist[lane] = 0; }
+    for (int i = lane; i < 5 * n; i += 64) { const int m = i / n, p = i - m * n; G->cm[m].cbf[0][p] = G->cm[m].cbf[1][p] = 0; G->cm[m].tskip[0][p] = G->cm[m].tskip[1][p] = 0; }
+  }
+  /* ---- walk the luma TU tree; chroma leaves in z-order ---- */
   TU st[4]; int ci[4]; int sp = 0;
-  st[0] = root; ci[0] = -1;
+  tu_root(st[0], d); ci[0] = -1;
   while (sp >= 0) {
-    const TU tu = st[sp];
     if (ci[sp] < 0) {
-      if (tu.cw == 0) { sp--; continue; }
-      if (cu->tr_idx[tu.part] == tu.tr_depth) {
-        const int N = tu.cw, layer = LOG2_MAXTU - tu.log2;
-        FCU_FOR_LANES {
-          for (int i = lane; i < N * N; i += 64) {
-            const int yy = tu.cy + i / N, xx = tu.cx + i % N;
-            cu->coef[1][tu.off_c + i] = G->qt_coef[1][layer][tu.off_c + i]; cu->coef[2][tu.off_c + i] = G->qt_coef[2][layer][tu.off_c + i];
-            reco->u[yy * 32 + xx] = G->qt_rec[layer].u[yy * 32 + xx]; reco->v[yy * 32 + xx] = G->qt_rec[layer].v[yy * 32 + xx];
+      const TU tu = st[sp];
+      const int subdiv = cu->tr_idx[tu.part] > tu.tr_depth;
+      if (!subdiv) {
+        if (tu.cw != 0) {
+          const int N = tu.cw, log2 = ilog2(N), n2 = N * N, trDepth = tu.tr_depth;
+          int checkTS = P.transform_skip && N <= 4;
+          if (P.ts_fast) {
+            checkTS = checkTS && (tu.log2 == 2);
+            if (checkTS) { int nb = 0; const int maxp = tu.part + (tu.c_code_all ? 1 : 4); for (int p = tu.part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
+          }
+          const int tsv = checkTS ? 2 : 1, nvc = 5 * tsv;
+          const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
+          for (int comp = 1; comp < 3; comp++) {
+            const int px = (cu->x >> 1) + tu.cx, py = (cu->y >> 1) + tu.cy;
+            const uint8_t *org = yuv_plane(&G->org[d], comp) + tu.cy * 32 + tu.cx;
+            chroma_leaf_refs5(E, cu, comp, px, py, log2);
+            FCU_FOR_LANES {
+              for (int i = lane; i < 5 * n2; i += 64) {
+                const int m = i / n2, p = i - m * n2, y = p >> log2, x = p & (N - 1);
+                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const int pr = pred_pixel(S->ref5[m], log2, mode, 0, S->dc5[m], x, y);
+                G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
+              }
+            }
+            FCU_FOR_LANES { for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1(G->p_resi + m * n2, log2, 0, i - m * n2); } }
+            FCU_FOR_LANES {
+              for (int i = lane; i < nvc * n2; i += 64) {
+                const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
+                G->p_tcoef[i] = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + m * n2, log2, 0, p);
+              }
+            }
+            FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
+              if (lane < nvc) {
+                const int m = lane / tsv;
+                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
+                S->vc_abs[lane] = rdoq(&S->lane[m], G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
+                S->vc_dist[lane] = 0;
+              }
+              if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
+            }
+            FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = S->vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp_c) : 0; } }
+            FCU_FOR_LANES {
+              for (int i = lane; i < nvc * n2; i += 64) {
+                const int v = i / n2, p = i - v * n2, ts = v % tsv;
+                if (ts) { const int sft = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (sft - 1))) >> sft; }
+                else G->p_tcoef[i] = inv1(G->p_tmp + v * n2, log2, 0, p);
+              }
+            }
+            FCU_FOR_LANES {
+              for (int i = lane; i < nvc * n2; i += 64) {
+                const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+                int res = 0;
+                if (S->vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, 0, p);
+                const int r = clip8(G->p_pred[m * n2 + p] + res);
+                G->p_rec[i] = (uint8_t)r;
+                const int e = org[y * 32 + x] - r;
+                FCU_ATOMIC_ADD(&S->vc_dist[v], (uint32_t)(e * e));
+              }
+            }
+            FCU_FOR_LANES {                                      /* per mode: transform-skip decision (TEncSearch.cpp:1985-2058) */
+              if (lane < 5) {
+                const int m = lane; int bestTs = 0;
+                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                uint32_t dsel = (uint32_t)(P.chroma_weight * (double)S->vc_dist[m * tsv]);
+                if (tsv == 2) {
+                  const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)S->vc_dist[m * 2 + 1]);
+                  Cabac *c0 = &S->lane[5 + m], *c1 = &S->lane[10 + m];
+                  cab_copy1(c0, &S->lane[m]); cab_reset_bits(c0);
+                  if (S->vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qcoef + (m * 2) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 0, P, S->lane_abs[lane]);
+                  const double cost0 = rd_cost(P, cab_bits(c0), d0);
+                  double cost1 = FCU_MAX_DOUBLE;
+                  if (S->vc_abs[m * 2 + 1] > 0) {
+                    cab_copy1(c1, &S->lane[m]); cab_reset_bits(c1);
+                    code_coeff_nxn(c1, G->p_qcoef + (m * 2 + 1) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 1, P, S->lane_abs[lane]);
+                    cost1 = rd_cost(P, cab_bits(c1), d1);
+                  }
+                  if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&S->lane[m], c1); } else cab_copy1(&S->lane[m], c0);
+                }
+                S->uni[m] = bestTs;
+                S->cm_dist[m] += dsel;
+              }
+            }
+            FCU_FOR_LANES {                                      /* publish the chosen variant into the mode's buffers */
+              for (int i = lane; i < 5 * n2; i += 64) {
+                const int m = i / n2, p = i - m * n2, v = m * tsv + S->uni[m], cbf = S->vc_abs[v] > 0;
+                G->cm[m].coef[comp - 1][tu.off_c + p] = cbf ? G->p_qcoef[v * n2 + p] : (int16_t)0;
+                uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
+                ov[(tu.cy + (p >> log2)) * 32 + tu.cx + (p & (N - 1))] = G->p_rec[v * n2 + p];
+              }
+              for (int i = lane; i < 5 * nPartsC; i += 64) {
+                const int m = i / nPartsC, p = i - m * nPartsC, v = m * tsv + S->uni[m];
+                G->cm[m].cbf[comp - 1][subPart + p] = (uint8_t)((S->vc_abs[v] > 0 ? 1 : 0) << trDepth);
+                G->cm[m].tskip[comp - 1][subPart + p] = (uint8_t)S->uni[m];
+              }
+            }
           }
         }
         sp--; continue;
@@ -1521,35 +1680,48 @@ FCU_DEV FCU_NOINLINE void set_intra_result_chroma_qt(const Env &E, CuObj *cu, co
     if (ci[sp] >= 4) { sp--; continue; }
     { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
   }
-}
-FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
-{
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
-  const int d = cu->depth_cu, n = cu->nparts;
-  TU tu; tu_root(tu, d);
-  Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
-  FCU_SERIAL { S->c_best_cost = FCU_MAX_DOUBLE; S->c_best_mode = 0; S->c_best_dist = 0; }
-  int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
-  { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
-  for (int m = 0; m < 5; m++) {
-    const int mode = modeList[m];
-    FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); for (int i = lane; i < n; i += 64) cu->intra_dir[1][i] = (uint8_t)mode; if (lane == 0) S->c_dist = 0; }
-    recur_chroma_qt<0>(E, cu, tu);
-    FCU_FOR_LANES { if (P.transform_skip) cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); }
-    FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 0, 1); }
-    const uint32_t dist = S->c_dist;
-    const double cost = rd_cost(P, S->vc_bits[0], dist);
-    if (cost < S->c_best_cost) {
-      FCU_SERIAL { S->c_best_cost = cost; S->c_best_dist = dist; S->c_best_mode = mode; }
-      set_intra_result_chroma_qt(E, cu, tu, recoT);
-      FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { G->tmpc_cbf[0][i] = cu->cbf[1][i]; G->tmpc_cbf[1][i] = cu->cbf[2][i]; G->tmpc_tskip[0][i] = cu->tskip[1][i]; G->tmpc_tskip[1][i] = cu->tskip[2][i]; } }
+  /* ---- per mode: CBF propagation up the tree, bits, cost ---- */
+  FCU_FOR_LANES {
+    if (lane < 5) {
+      const int m = lane; ChromaModeBuf *B = &G->cm[m];
+      for (int t = 2; t >= 0; t--) {                            /* nodes of relative depth t, deepest first */
+        const int np = n >> (2 * t);
+        if (np < 4) continue;
+        for (int part = 0; part < n; part += np) {
+          if (!(cu->tr_idx[part] > t)) continue;
+          for (int k = 0; k < 2; k++) {
+            int any = 0;
+            for (int q = 0; q < 4; q++) any |= (B->cbf[k][part + q * (np >> 2)] >> (t + 1)) & 1;
+            if (any) for (int o = 0; o < np; o++) B->cbf[k][part + o] |= (uint8_t)(1 << t);
+          }
+        }
+      }
+      Cabac *c = &S->lane[5 + m];
+      cab_copy1(c, &S->slot[d][CI_CURR_BEST]);
+      S->vc_bits[m] = chroma_tree_bits(E, c, cu, m, modeList[m], S->lane_abs[lane]);
+      S->vc_cost[m] = rd_cost(P, S->vc_bits[m], S->cm_dist[m]);
     }
   }
-  const int bm = S->c_best_mode; const uint32_t bd = S->c_best_dist;
-  FCU_FOR_LANES {
-    for (int i = lane; i < n; i += 64) { cu->cbf[1][i] = G->tmpc_cbf[0][i]; cu->cbf[2][i] = G->tmpc_cbf[1][i]; cu->tskip[1][i] = G->tmpc_tskip[0][i]; cu->tskip[2][i] = G->tmpc_tskip[1][i]; cu->intra_dir[1][i] = (uint8_t)bm; }
-    if (lane == 0) cu->dist += bd;
-    cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane);
+  FCU_SERIAL {
+    double best = FCU_MAX_DOUBLE; int bm = 0;
+    for (int m = 0; m < 5; m++) if (S->vc_cost[m] < best) { best = S->vc_cost[m]; bm = m; }
+    S->c_best_mode = bm;
+  }
+  {
+    const int bm = S->c_best_mode; const ChromaModeBuf *B = &G->cm[bm];
+    Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+    FCU_FOR_LANES {
+      for (int i = lane; i < cs * cs; i += 64) {
+        cu->coef[1][i] = B->coef[0][i]; cu->coef[2][i] = B->coef[1][i];
+        const int o = (i / cs) * 32 + (i % cs); recoT->u[o] = B->u[o]; recoT->v[o] = B->v[o];
+      }
+      for (int i = lane; i < n; i += 64) {
+        cu->cbf[1][i] = B->cbf[0][i]; cu->cbf[2][i] = B->cbf[1][i]; cu->tskip[1][i] = B->tskip[0][i]; cu->tskip[2][i] = B->tskip[1][i];
+        cu->intra_dir[1][i] = (uint8_t)modeList[bm];
+      }
+      if (lane == 0) cu->dist += S->cm_dist[bm];
+      cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane);
+    }
   }
 }
 
@@ -1578,7 +1750,8 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
     const Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
     FCU_FOR_LANES { uint8_t *p = E.C->rec[0] + cu->y * E.C->stride[0] + cu->x; const int rs = E.C->stride[0]; for (int i = lane; i < s * s; i += 64) p[(i / s) * rs + (i % s)] = recoT->y[(i / s) * 64 + (i % s)]; }
   }
-  est_intra_pred_chroma(E, cu);
+  { FCU_TIC(t_); est_intra_pred_chroma(E, cu); FCU_TOC(E, t_, 6); }
+  FCU_TIC(t7_);
   FCU_FOR_LANES {
     if (lane == 0) {
       cab_reset_bits(&S->goon);
@@ -1588,6 +1761,7 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
     }
   }
   FCU_FOR_LANES cab_copy(&S->slot[d][CI_TEMP_BEST], &S->goon, lane);
+  FCU_TOC(E, t7_, 7);
   check_best_mode(E, d);
 }
 
@@ -1690,6 +1864,7 @@ FCU_DEV FCU_NOINLINE void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, i
 FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuRsAddr)
 {
   Env E; E.C = C; E.G = G; E.S = S;
+  FCU_TIC(t10_);
   const Params &P = C->p;
   const int sliceLen = P.slice_ctus > 0 ? P.slice_ctus : C->n_ctu;
   const int sliceStart = (ctuRsAddr / sliceLen) * sliceLen;
@@ -1727,12 +1902,15 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
       for (int i = lane; i < 1024; i += 64) { view->coef[1][i] = (int16_t)out->coeff_cb[i]; view->coef[2][i] = (int16_t)out->coeff_cr[i]; }
       cab_copy(&S->goon, &S->slot[0][CI_CURR_BEST], lane);
     }
+    FCU_TIC(t9_);
     FCU_SERIAL {
       cab_reset_bits(&S->goon);
       encode_ctu(E, &S->goon, view, ctuRsAddr == sliceEnd - 1);
       cab_copy1(&C->state, &S->goon);
     }
+    FCU_TOC(E, t9_, 9);
   }
+  FCU_TOC(E, t10_, 10);
 }
 
 } // namespace fcu

@@ -162,6 +162,19 @@ int fcu_compress_ctu(fcu_ctx *c, int chain, uint32_t ctuRsAddr, fcu_ctu_out *hos
   return FCU_OK;
 }
 
+/* diagnostic: per-chain section timers (only meaningful in a -DFCU_PROFILE build) and TU-trial count */
+int fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !out17) return fail(FCU_ERR_ARG, "fcu_debug_counters: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  Chain h;
+  HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) out17[i] = h.prof[i];
+  out17[16] = h.n_tu_trials;
+  return FCU_OK;
+}
+
 int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bits)
 {
   if (!c || chain < 0 || chain >= c->sp.max_chains || !ctx160 || !frac_bits) return fail(FCU_ERR_ARG, "fcu_get_ctx_state: bad argument");

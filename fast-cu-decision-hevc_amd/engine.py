@@ -49,7 +49,7 @@ CTU_OUT_BYTES = C.sizeof(CtuOut)
 
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
-           "fcu_kernel_ms", "fcu_last_error"]
+           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters"]
 
 
 def lib_path():
@@ -81,6 +81,7 @@ def load_lib():
     lib.fcu_sync.argtypes = [C.c_void_p]
     lib.fcu_kernel_ms.restype = C.c_double
     lib.fcu_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.fcu_debug_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.fcu_last_error.restype = C.c_char_p
     _lib = lib
     return lib
@@ -167,6 +168,11 @@ class CuEngine:
         n = C.c_int(0)
         ms = self.lib.fcu_kernel_ms(self.h, C.byref(n))
         return ms, n.value
+
+    def debug_counters(self, chain):
+        buf = (C.c_ulonglong * 17)()
+        self._chk(self.lib.fcu_debug_counters(self.h, chain, buf), "fcu_debug_counters")
+        return list(buf)
 
     def position(self, chain):
         return self.lib.fcu_chain_position(self.h, chain)

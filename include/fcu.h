@@ -90,6 +90,9 @@ int  fcu_sync(fcu_ctx *c);
 /* average duration (ms) of the engine kernel launches recorded with HIP events on the launch
  * stream since the last call; resets the accumulator */
 double fcu_kernel_ms(fcu_ctx *c, int *launches);
+/* diagnostic counters of a chain: out17[0..15] section timers (shader clocks, -DFCU_PROFILE builds only),
+ * out17[16] = TU trials so far */
+int  fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17);
 const char *fcu_last_error(void);
 
 #ifdef __cplusplus

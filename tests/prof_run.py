@@ -1,0 +1,31 @@
+import sys, os, ctypes as C, time
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
+import __graft_entry__ as g
+pkg = g.load_package()
+import torch
+from bench import gen_textured_gpu
+# swap in the profiling library
+pkg.engine._lib = None
+pkg.engine.lib_path = lambda: os.path.join(os.path.dirname(pkg.engine.__file__), 'libfcu_prof.so')
+W,H = 3840,2160
+frames = int(sys.argv[1]) if len(sys.argv)>1 else 64
+nct = int(sys.argv[2]) if len(sys.argv)>2 else 2
+qps=[22,27,32,37]
+eng = pkg.CuEngine(W,H,max_chains=frames*4)
+dev=torch.device('cuda',0)
+ci=0
+for f in range(frames):
+    fr=gen_textured_gpu(torch,dev,W,H,seed=7+f)
+    for qp in qps:
+        out=torch.zeros(pkg.engine.CTU_OUT_BYTES*nct,dtype=torch.uint8,device=dev)
+        eng.init_chain(ci,fr,qp=qp,out=out); ci+=1
+t=time.time(); eng.compress_chains(0,frames*4,nct); eng.sync(); dt=time.time()-t
+print('chains',frames*4,'ctus',nct,'time',dt,'CTU/s',frames*4*nct/dt)
+names=['rmd','pass1_total','pass1_rdoq','pass1_bits','pass2_rqt','chroma_batched','chroma_total','cu_syntax','seq_rdoq','replay','ctu_total']
+import numpy as np
+acc=np.zeros(17)
+for c in range(0,frames*4,max(1,frames*4//64)):
+    acc+=np.array(eng.debug_counters(c),dtype=float)
+tot=acc[10]
+for i,n in enumerate(names): print('%-16s %6.2f%%'%(n,100*acc[i]/tot))
+print('tu trials/CTU', acc[16]/ (len(range(0,frames*4,max(1,frames*4//64)))*nct))
