@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU (x4 QPs = chains per GPU)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU (x4 QPs = chains per GPU)")
     ap.add_argument("--ctus-per-step", type=int, default=1)
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -114,6 +114,7 @@ struct Scratch {
   int16_t ts_coef[3][1024]; Yuv ts_rec; uint8_t shared_pred[3][1024];
   uint8_t tmp_tr_idx[NPART], tmp_cbf[NPART], tmp_tskip[NPART];
   ChromaModeBuf cm[5];
+  Cabac slots[MAXDEPTH + 2][CI_NUM];               /* the colder snapshots (NEXT/TEMP_BEST, QT_TRAFO_*) live in L2 */
   /* candidate pools: slot v occupies [v*N*N, (v+1)*N*N) */
   uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; int16_t p_qcoef[POOL]; uint8_t p_rec[POOL];
   /* RDOQ locals (TComTrQuant.cpp:2082-2095) */
@@ -123,13 +124,13 @@ struct Scratch {
 /* per-chain LDS */
 struct Shared {
   Cabac goon;
-  Cabac slot[MAXDEPTH + 2][CI_NUM];
+  Cabac cur[MAXDEPTH + 1];                         /* [depth][CI_CURR_BEST]: read by every trial of the CU being decided */
   Cabac lane[MAXVC];
   uint8_t ref[264], reff[264];
   uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
   int16_t lane_abs[MAXVC][16];                      /* per-lane |level| list of the coefficient group being coded */
   int16_t diff[DIFFN];
-  int32_t colsum[256];
+  int32_t colsum[128];
   uint32_t sad[36];
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
@@ -149,6 +150,7 @@ struct Shared {
 };
 
 struct Env { Chain *C; Scratch *G; Shared *S; int cur_ctu, slice_start; };
+FCU_DEV Cabac *slot_ptr(const Env &E, int d, int ci) { return ci == CI_CURR_BEST ? &E.S->cur[d] : &E.G->slots[d][ci]; }
 
 /* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
 struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
@@ -1112,7 +1114,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
 
   if (checkFull) {
     if (checkTS) {
-      FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
       for (int modeId = 0; modeId < 2; modeId++) {
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)modeId; }
         tu_trial(E, cu, tu, 0, &S->goon, modeId == 0 ? 1 : 2);
@@ -1125,17 +1127,17 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
         }
         if (tmpCost < singleCost) {
           singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
-          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_TEMP_BEST], &S->goon, lane); }
+          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &S->goon, lane); }
         }
-        if (modeId == 0) FCU_FOR_LANES cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
+        if (modeId == 0) FCU_FOR_LANES cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)bestModeId; }
       if (bestModeId == 0) {
         load_intra_result_qt(E, cu, tu, 0);
-        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&S->goon, &S->slot[fullDepth][CI_TEMP_BEST], lane); }
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_TEMP_BEST), lane); }
       }
     } else {
-      if (checkSplit) FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      if (checkSplit) FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = 0; }
       if (reuseVc >= 0) {
         /* the un-split trial of the re-run (TEncSearch.cpp:2518-2586) repeats the first-pass trial of the same mode
@@ -1162,8 +1164,8 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
   }
   if (checkSplit) {
     if constexpr (LEVEL < 3) {
-      if (checkFull) { FCU_FOR_LANES { cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_TEST], &S->goon, lane); } FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane); } }
-      else FCU_FOR_LANES cab_copy(&S->slot[fullDepth][CI_QT_TRAFO_ROOT], &S->goon, lane);
+      if (checkFull) { FCU_FOR_LANES { cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), &S->goon, lane); } FCU_FOR_LANES { cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane); } }
+      else FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
       FCU_SERIAL { S->q_dist[LEVEL + 1] = 0; S->q_cost[LEVEL + 1] = 0; }
       uint32_t splitCbf = 0;
       for (int i = 0; i < 4; i++) {
@@ -1174,13 +1176,13 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
       const uint32_t splitDist = S->q_dist[LEVEL + 1];
       FCU_FOR_LANES {
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
-        cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_ROOT], lane);
+        cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
       FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
       const double splitCost = rd_cost(P, S->vc_bits[0], splitDist);
       if (splitCost < singleCost) { FCU_SERIAL { S->q_dist[LEVEL] += splitDist; S->q_cost[LEVEL] += splitCost; } return; }
       FCU_FOR_LANES {
-        cab_copy(&S->goon, &S->slot[fullDepth][CI_QT_TRAFO_TEST], lane);
+        cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), lane);
         for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cu->tskip[0][part + i] = (uint8_t)bestModeId; }
         const int N = 1 << log2, layer = LOG2_MAXTU - log2;
         const uint8_t *s = G->qt_rec[layer].y + tu.y * 64 + tu.x;
@@ -1230,7 +1232,7 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
   build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   const int usz = N >= 8 ? 8 : 4, ul = usz == 8 ? 3 : 2, upix = usz * usz, bpr = N / usz, nblk = bpr * bpr;
-  const int totalUnits = 35 * nblk, K = DIFFN / upix;
+  const int totalUnits = 35 * nblk, K = (DIFFN / upix) < (128 / usz) ? (DIFFN / upix) : (128 / usz);
   FCU_FOR_LANES { if (lane < 36) S->sad[lane] = 0; }
   for (int u0 = 0; u0 < totalUnits; u0 += K) {
     const int nu = (totalUnits - u0) < K ? (totalUnits - u0) : K;
@@ -1273,7 +1275,7 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
     int preds[3];
     const int nm = intra_dir_predictor(E, cu, tu.part, preds);
     S->preds[0] = preds[0]; S->preds[1] = preds[1]; S->preds[2] = preds[2]; S->n_mpm = nm;
-    const Cabac *cb = &S->slot[d][CI_CURR_BEST];
+    const Cabac *cb = slot_ptr(E, d, CI_CURR_BEST);
     const uint64_t carry = cb->frac & 32767;               /* loadIntraDirMode + resetBits, TEncSearch.cpp:5313-5340 */
     int numFull = k_rd_mode_num[log2 - 2];
     double candCost[12];
@@ -1339,7 +1341,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
       const int mode = S->rd_mode[lane / tsv];
       RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      S->vc_abs[lane] = rdoq(&S->slot[d][CI_CURR_BEST], G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
+      S->vc_abs[lane] = rdoq(slot_ptr(E, d, CI_CURR_BEST), G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
       S->vc_dist[lane] = 0;
     }
     if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
@@ -1372,7 +1374,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
       if (ts && !cbf) cost = FCU_MAX_DOUBLE;                 /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
       else {
         Cabac *c = &S->lane[lane];
-        cab_copy1(c, &S->slot[d][CI_CURR_BEST]);
+        cab_copy1(c, slot_ptr(E, d, CI_CURR_BEST));
         cab_reset_bits(c);
         if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
         code_luma_dir_bits(c, mode, S->preds);
@@ -1431,7 +1433,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
       const int nc = S->n_rd;
       for (int m = 0; m < nc; m++) {
         const int orgMode = S->rd_mode[m];
-        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
         recur_luma_qt<0>(E, cu, tu, 1);
         if (S->q_cost[0] < S->pu_best_cost) {
           FCU_SERIAL { S->pu_best_mode = orgMode; S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
@@ -1445,7 +1447,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
      * earlier result, so it is skipped. */
     if (log2 > min_tu_log2_in_cu(d, partSize)) {
       const int orgMode = S->pu_best_mode;
-      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
+      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
       { FCU_TIC(t_); recur_luma_qt<0>(E, cu, tu, 0, singleTU ? S->pu_best_vc : -1); FCU_TOC(E, t_, 4); }
       if (S->q_cost[0] < S->pu_best_cost) {
         FCU_SERIAL { S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
@@ -1473,7 +1475,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
       for (int o = 0; o < 4 * qNumParts; o++) { cu->cbf[0][o] |= cy; cu->cbf[1][o] |= cu1; cu->cbf[2][o] |= cv; }
     }
   }
-  FCU_FOR_LANES { cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane); if (lane == 0) cu->dist = overallDistY; }
+  FCU_FOR_LANES { cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) cu->dist = overallDistY; }
 }
 
 /* ======================================================================================== */
@@ -1567,7 +1569,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
   int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
   { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
   FCU_FOR_LANES {
-    if (lane < 5) { cab_copy1(&S->lane[lane], &S->slot[d][CI_CURR_BEST]); S->cm_dist[lane] = 0; }
+    if (lane < 5) { cab_copy1(&S->lane[lane], slot_ptr(E, d, CI_CURR_BEST)); S->cm_dist[lane] = 0; }
     for (int i = lane; i < 5 * n; i += 64) { const int m = i / n, p = i - m * n; G->cm[m].cbf[0][p] = G->cm[m].cbf[1][p] = 0; G->cm[m].tskip[0][p] = G->cm[m].tskip[1][p] = 0; }
   }
   /* ---- walk the luma TU tree; chroma leaves in z-order ---- */
@@ -1697,7 +1699,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
         }
       }
       Cabac *c = &S->lane[5 + m];
-      cab_copy1(c, &S->slot[d][CI_CURR_BEST]);
+      cab_copy1(c, slot_ptr(E, d, CI_CURR_BEST));
       S->vc_bits[m] = chroma_tree_bits(E, c, cu, m, modeList[m], S->lane_abs[lane]);
       S->vc_cost[m] = rd_cost(P, S->vc_bits[m], S->cm_dist[m]);
     }
@@ -1720,7 +1722,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
         cu->intra_dir[1][i] = (uint8_t)modeList[bm];
       }
       if (lane == 0) cu->dist += S->cm_dist[bm];
-      cab_copy(&S->goon, &S->slot[d][CI_CURR_BEST], lane);
+      cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane);
     }
   }
 }
@@ -1736,7 +1738,7 @@ FCU_DEV FCU_NOINLINE void check_best_mode(const Env &E, int d)
   Shared *S = E.S;
   const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
   FCU_FOR_LANES {
-    if (change) { cab_copy(&S->slot[d][CI_NEXT_BEST], &S->slot[d][CI_TEMP_BEST], lane); if (lane == 0) { S->best_idx[d] = 1 - S->best_idx[d]; S->reco_best_idx[d] = 1 - S->reco_best_idx[d]; } }
+    if (change) { cab_copy(slot_ptr(E, d, CI_NEXT_BEST), slot_ptr(E, d, CI_TEMP_BEST), lane); if (lane == 0) { S->best_idx[d] = 1 - S->best_idx[d]; S->reco_best_idx[d] = 1 - S->reco_best_idx[d]; } }
   }
 }
 FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
@@ -1760,7 +1762,7 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
       cu->cost = rd_cost(P, cu->bits, cu->dist);
     }
   }
-  FCU_FOR_LANES cab_copy(&S->slot[d][CI_TEMP_BEST], &S->goon, lane);
+  FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &S->goon, lane);
   FCU_TOC(E, t7_, 7);
   check_best_mode(E, d);
 }
@@ -1803,7 +1805,7 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
       cu_init(E, &G->cu[nd][0], nd, sx, sy, zidx + i * qn);
       cu_init(E, &G->cu[nd][1], nd, sx, sy, zidx + i * qn);
       if (sx < P.width && sy < P.height) {
-        FCU_FOR_LANES cab_copy(&S->slot[nd][CI_CURR_BEST], i == 0 ? &S->slot[D][CI_CURR_BEST] : &S->slot[nd][CI_NEXT_BEST], lane);
+        FCU_FOR_LANES cab_copy(slot_ptr(E, nd, CI_CURR_BEST), i == 0 ? slot_ptr(E, D, CI_CURR_BEST) : slot_ptr(E, nd, CI_NEXT_BEST), lane);
         compress_cu<D + 1>(E);
         cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
         {                                                    /* xCopyYuv2Tmp */
@@ -1824,7 +1826,7 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
       if (!boundary) { cab_reset_bits(&S->goon); code_split_flag(E, &S->goon, t, 0, D); t->bits += cab_bits(&S->goon); t->bins += S->goon.bins; }
       t->cost = rd_cost(P, t->bits, t->dist);
     }
-    FCU_FOR_LANES cab_copy(&S->slot[D][CI_TEMP_BEST], &S->slot[nd][CI_NEXT_BEST], lane);
+    FCU_FOR_LANES cab_copy(slot_ptr(E, D, CI_TEMP_BEST), slot_ptr(E, nd, CI_NEXT_BEST), lane);
     check_best_mode(E, D);
   }
   cu_copy_to_pic(E, cu_best(E, D));
@@ -1872,7 +1874,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
   E.cur_ctu = ctuRsAddr; E.slice_start = sliceStart;
   fcu_ctu_out *out = &C->out[ctuRsAddr];
   const int x = (ctuRsAddr % C->w_ctu) * CTU, y = (ctuRsAddr / C->w_ctu) * CTU;
-  FCU_SERIAL { if (ctuRsAddr == sliceStart) cab_init(&S->slot[0][CI_CURR_BEST], P.qp); else cab_copy1(&S->slot[0][CI_CURR_BEST], &C->state); }
+  FCU_SERIAL { if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
   FCU_FOR_LANES {                                            /* TComDataCU::initCtu defaults, TComDataCU.cpp:474-560 */
     for (int i = lane; i < NPART; i += 64) {
       out->depth[i] = 0; out->width[i] = CTU; out->height[i] = CTU; out->skip[i] = 0; out->part_size[i] = SIZE_NONE; out->pred_mode[i] = MODE_NONE;
@@ -1882,7 +1884,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
     }
     for (int i = lane; i < 4096; i += 64) out->coeff_y[i] = 0;
     for (int i = lane; i < 1024; i += 64) { out->coeff_cb[i] = 0; out->coeff_cr[i] = 0; }
-    cab_copy(&S->goon, &S->slot[0][CI_CURR_BEST], lane);
+    cab_copy(&S->goon, slot_ptr(E, 0, CI_CURR_BEST), lane);
     if (lane == 0) { for (int d = 0; d < 4; d++) { S->best_idx[d] = 0; S->reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
   }
   cu_init(E, &G->cu[0][0], 0, x, y, 0);
@@ -1900,7 +1902,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
       }
       for (int i = lane; i < 4096; i += 64) view->coef[0][i] = (int16_t)out->coeff_y[i];
       for (int i = lane; i < 1024; i += 64) { view->coef[1][i] = (int16_t)out->coeff_cb[i]; view->coef[2][i] = (int16_t)out->coeff_cr[i]; }
-      cab_copy(&S->goon, &S->slot[0][CI_CURR_BEST], lane);
+      cab_copy(&S->goon, slot_ptr(E, 0, CI_CURR_BEST), lane);
     }
     FCU_TIC(t9_);
     FCU_SERIAL {
