@@ -54,6 +54,15 @@
 
 #include "fcu_tables.h"
 
+/* hot tables mirrored in LDS (the per-bin cost/transition table is read once per context-coded bin and several
+ * times per RDOQ coefficient; on-chip reads keep the vector-memory pipeline for the scratch traffic) */
+struct HotTables { uint32_t bin[256]; uint16_t scan[3][16 + 64]; uint8_t scan_cg8[3][4]; uint8_t ctx_ind_map4x4[16]; uint8_t group_idx[32]; };
+#ifdef FCU_EMU
+static HotTables g_hot;
+#else
+__shared__ HotTables g_hot;
+#endif
+
 namespace fcu {
 
 /* ---- constants ------------------------------------------------------------------------ */
@@ -65,7 +74,7 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
        CTX_TSKIP = 157, NCTX = 160 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
-enum { MAXVC = 20, POOL = 5120, DIFFN = 1024 };
+enum { MAXVC = 20, POOL = 5120, DIFFN = 512 };
 #define FCU_MAX_DOUBLE 1.7e+308
 
 /* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
@@ -214,16 +223,16 @@ FCU_DEV void cab_copy1(Cabac *d, const Cabac *s)              /* single-lane cop
 { const uint32_t *a = (const uint32_t *)s; uint32_t *b = (uint32_t *)d; for (int i = 0; i < (int)(sizeof(Cabac) / 4); i++) b[i] = a[i]; }
 FCU_DEV void cab_bin(Cabac *c, int bin, int ctx)
 {
-  uint8_t s = c->ctx[ctx];
+  const uint32_t e = g_hot.bin[c->ctx[ctx] * 2 + bin];         /* (bits << 8) | next state */
   c->bins++;
-  c->frac += (uint64_t)k_entropy_bits[s ^ bin];
-  c->ctx[ctx] = k_next_state[s * 2 + bin];
+  c->frac += (uint64_t)(e >> 8);
+  c->ctx[ctx] = (uint8_t)e;
 }
 FCU_DEV void cab_ep(Cabac *c, int n) { c->bins += (uint32_t)n; c->frac += (uint64_t)32768 * (uint64_t)n; }
 FCU_DEV void cab_trm(Cabac *c, int bin) { c->bins++; c->frac += (uint64_t)k_entropy_bits[126 ^ bin]; }
 FCU_DEV void cab_reset_bits(Cabac *c) { c->frac &= 32767; c->bins = 0; }
 FCU_DEV uint32_t cab_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
-FCU_DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return k_entropy_bits[c->ctx[ctx] ^ bin]; }
+FCU_DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return (int)(g_hot.bin[c->ctx[ctx] * 2 + bin] >> 8); }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -256,7 +265,7 @@ FCU_DEV int sig_ctx_inc(int pattern, int first, int pos, int log2, int ch)     /
   const int py = pos >> log2, px = pos - (py << log2);
   if (px + py == 0) return 0;
   int offset;
-  if (log2 == 2) offset = k_ctx_ind_map4x4[4 * py + px];
+  if (log2 == 2) offset = g_hot.ctx_ind_map4x4[4 * py + px];
   else {
     int cnt; const int xs = px & 3, ys = py & 3;
     if (pattern == 0) { int t = xs + ys; cnt = (t >= 3) ? 0 : ((t >= 1) ? 1 : 2); }
@@ -286,8 +295,8 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
   for (int i = 0; i < n2; i++) numSig += coef[i] != 0;
   if (numSig == 0) return;                                    /* never called on empty TUs */
   if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
-  const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
-  const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
+  const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
   int scanPosLast = -1, posLast;
@@ -298,9 +307,9 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
   {
     int py = posLast >> log2, px = posLast - (py << log2);
     if (scanType == 2) { int t = px; px = py; py = t; }
-    const int gx = k_group_idx[px], gy = k_group_idx[py], cc = log2 - 2;
+    const int gx = g_hot.group_idx[px], gy = g_hot.group_idx[py], cc = log2 - 2;
     const int off = ch ? 0 : (cc * 3 + ((cc + 1) >> 2)), sh = ch ? cc : ((cc + 3) >> 2);
-    const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = k_group_idx[N - 1];
+    const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = g_hot.group_idx[N - 1];
     int k;
     for (k = 0; k < gx; k++) cab_bin(c, 1, bx + (k >> sh));
     if (gx < gmax) cab_bin(c, 0, bx + (k >> sh));
@@ -362,7 +371,8 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2
 /* ======================================================================================== */
 struct RdoqBuf { double *cc, *cs, *c0; int32_t *up, *dn, *sd, *du; double *cg; };
 
-FCU_DEV int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
+struct LevelBits { int g10, g11, g20, g21; };              /* greater1 / greater2 flag costs of the current contexts */
+FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
 {                                                          /* xGetICRate, TComTrQuant.cpp:2807-2881 */
   int rate = 32768;
   const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
@@ -374,14 +384,14 @@ FCU_DEV int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, u
       while (symbol >= (1u << length)) symbol -= (1u << (length++));
       rate += (int)((3 + length + 1 - goRice + length) << 15);
     }
-    if (c1Idx < 8) { rate += ctx_bits(c, ctxOne, 1); if (c2Idx < 1) rate += ctx_bits(c, ctxAbs, 1); }
-  } else if (absLevel == 1) rate += ctx_bits(c, ctxOne, 0);
-  else if (absLevel == 2) { rate += ctx_bits(c, ctxOne, 1); rate += ctx_bits(c, ctxAbs, 0); }
+    if (c1Idx < 8) { rate += b.g11; if (c2Idx < 1) rate += b.g21; }
+  } else if (absLevel == 1) rate += b.g10;
+  else if (absLevel == 2) { rate += b.g11; rate += b.g20; }
   else rate = 0;
   return rate;
 }
 FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
-                             int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, int ctxOne, int ctxAbs,
+                             int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, const LevelBits &lb,
                              uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last)
 {                                                          /* xGetCodedLevel, TComTrQuant.cpp:2738-2794 */
   double currCostSig = 0; uint32_t bestAbs = 0;
@@ -394,7 +404,7 @@ FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, d
   const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
   for (int a = (int)maxAbsLevel; a >= (int)minAbs; a--) {
     double err = (double)(levelDouble - ((int32_t)a << qbits));
-    double cost = err * err * errScale + lambda * (double)ic_rate(c, (uint32_t)a, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+    double cost = err * err * errScale + lambda * (double)ic_rate(lb, (uint32_t)a, goRice, c1Idx, c2Idx);
     cost += currCostSig;
     if (cost < *codedCost) { bestAbs = (uint32_t)a; *codedCost = cost; *codedCostSig = currCostSig; }
   }
@@ -415,8 +425,8 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
   int32_t *rateIncUp = rb.up, *rateIncDown = rb.dn, *sigRateDelta = rb.sd, *deltaU = rb.du;
   /* the reference clears all seven arrays; only entries at scan positions <= the last significant one are
    * ever read back (last-position search, group zero-out, sign hiding), and each of those is written below */
-  const uint16_t *scan = k_scan + k_scan_off[scanType * 4 + log2 - 2];
-  const uint8_t *scanCG = k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
+  const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
   double *costCGSig = rb.cg; uint64_t cgflag = 0;
@@ -450,20 +460,22 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
         uint32_t level;
         const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1, absCtx = CTX_ABS + (int)ctxSet + c2;
         int sdel = 0, rup, rdn = 0;
+        LevelBits lb; lb.g10 = ctx_bits(c, oneCtx, 0); lb.g11 = lb.g20 = lb.g21 = 0;
+        if (maxAbsLevel > 0) { lb.g11 = ctx_bits(c, oneCtx, 1); lb.g20 = ctx_bits(c, absCtx, 0); lb.g21 = ctx_bits(c, absCtx, 1); }
         if (scanPos == lastScanPos)
           level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                              sigOff, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 1);
+                              sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1);
         else {
           const int ctxSig = sigOff + sig_ctx_inc(pattern, firstSig, blk, log2, ch);
           level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                              ctxSig, oneCtx, absCtx, goRice, c1Idx, c2Idx, qbits, errScale, 0);
+                              ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0);
           sdel = ctx_bits(c, ctxSig, 1) - ctx_bits(c, ctxSig, 0);
         }
         if (level > 0) {
-          const int rateNow = ic_rate(c, level, oneCtx, absCtx, goRice, c1Idx, c2Idx);
-          rup = ic_rate(c, level + 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
-          rdn = ic_rate(c, level - 1, oneCtx, absCtx, goRice, c1Idx, c2Idx) - rateNow;
-        } else rup = ctx_bits(c, oneCtx, 0);
+          const int rateNow = ic_rate(lb, level, goRice, c1Idx, c2Idx);
+          rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateNow;
+          rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateNow;
+        } else rup = lb.g10;
         costCoeff[scanPos] = cc; costCoeff0[scanPos] = c0; costSig[scanPos] = cs;
         sigRateDelta[blk] = sdel; rateIncUp[blk] = rup; rateIncDown[blk] = rdn;
         deltaU[blk] = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
@@ -521,7 +533,7 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
   baseCost += lambda * (double)ctx_bits(c, cbfCtx, 1);
   /* estLastSignificantPositionBit (TEncSbac.cpp:1863-1923) evaluated on demand */
   const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
-  const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = k_group_idx[N - 1];
+  const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = g_hot.group_idx[N - 1];
   int foundLast = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos];
@@ -534,7 +546,7 @@ FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, 
         if (dst[blk]) {
           const int py = blk >> log2, px = blk - (py << log2);
           const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
-          const int gx = k_group_idx[ax], gy = k_group_idx[ay];
+          const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
           int bxs = 0, bys = 0;
           for (int k = 0; k < gx; k++) bxs += ctx_bits(c, lbx + (k >> lsh), 1);
           if (gx < lgmax) bxs += ctx_bits(c, lbx + (gx >> lsh), 0);
@@ -1859,6 +1871,18 @@ FCU_DEV FCU_NOINLINE void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, i
       stChild[sp]++;
       if (ctu->x + part_x(p) < P.width && ctu->y + part_y(p) < P.height) { sp++; stPart[sp] = p; stChild[sp] = -1; }
     }
+  }
+}
+
+/* cooperative fill of the LDS table mirror; called once per kernel launch */
+FCU_DEV void load_hot_tables()
+{
+  FCU_FOR_LANES {
+    for (int i = lane; i < 256; i += 64) g_hot.bin[i] = k_bin[i];
+    for (int i = lane; i < 3 * 80; i += 64) { const int t = i / 80, j = i % 80; g_hot.scan[t][j] = j < 16 ? k_scan[k_scan_off[t * 4 + 0] + j] : k_scan[k_scan_off[t * 4 + 1] + j - 16]; }
+    if (lane < 12) g_hot.scan_cg8[lane / 4][lane % 4] = k_scan_cg[k_scan_cg_off[(lane / 4) * 4 + 1] + lane % 4];
+    if (lane < 16) g_hot.ctx_ind_map4x4[lane] = k_ctx_ind_map4x4[lane];
+    if (lane < 32) g_hot.group_idx[lane] = k_group_idx[lane];
   }
 }
 

@@ -22,6 +22,7 @@ using namespace fcu;
  * (its SGPR spills would otherwise cost two extra VGPRs and the fourth wave per SIMD) */
 __device__ __noinline__ static void run_chain(Chain *C, Scratch *G, Shared *S, int ctus)
 {
+  load_hot_tables();
   for (int k = 0; k < ctus; k++) {
     const int a = C->next_ctu;
     if (a >= C->n_ctu || C->out == nullptr) break;          /* every wave reaches this exit */

@@ -25,6 +25,7 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, const uint8_
   e->c.stride[0] = width; e->c.stride[1] = e->c.stride[2] = width / 2;
   e->c.out = out;
   e->c.w_ctu = (width + 63) / 64; e->c.h_ctu = (height + 63) / 64; e->c.n_ctu = e->c.w_ctu * e->c.h_ctu;
+  load_hot_tables();
   e->g = (Scratch *)calloc(1, sizeof(Scratch));
   e->s = (Shared *)calloc(1, sizeof(Shared));
   return e;

@@ -6,7 +6,7 @@ import torch
 from bench import gen_textured_gpu
 # swap in the profiling library
 pkg.engine._lib = None
-pkg.engine.lib_path = lambda: os.path.join(os.path.dirname(pkg.engine.__file__), 'libfcu_prof.so')
+pkg.engine.lib_path = lambda: os.path.join(os.path.dirname(pkg.engine.__file__), os.environ.get('FCU_LIB','libfcu_prof.so'))
 W,H = 3840,2160
 frames = int(sys.argv[1]) if len(sys.argv)>1 else 64
 nct = int(sys.argv[2]) if len(sys.argv)>2 else 2
@@ -19,7 +19,10 @@ for f in range(frames):
     for qp in qps:
         out=torch.zeros(pkg.engine.CTU_OUT_BYTES*nct,dtype=torch.uint8,device=dev)
         eng.init_chain(ci,fr,qp=qp,out=out); ci+=1
-t=time.time(); eng.compress_chains(0,frames*4,nct); eng.sync(); dt=time.time()-t
+reps=int(os.environ.get('REPS','1'))
+t=time.time()
+for _ in range(reps): eng.compress_chains(0,frames*4,nct//reps)
+eng.sync(); dt=time.time()-t
 print('chains',frames*4,'ctus',nct,'time',dt,'CTU/s',frames*4*nct/dt)
 names=['rmd','pass1_total','pass1_rdoq','pass1_bits','pass2_rqt','chroma_batched','chroma_total','cu_syntax','seq_rdoq','replay','ctu_total']
 import numpy as np
