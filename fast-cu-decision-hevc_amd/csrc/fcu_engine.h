@@ -132,9 +132,9 @@ struct Scratch {
 
 /* per-chain LDS */
 struct Shared {
-  Cabac goon;
-  Cabac cur[MAXDEPTH + 1];                         /* [depth][CI_CURR_BEST]: read by every trial of the CU being decided */
-  Cabac lane[MAXVC];
+  /* hot coders, one LDS array so that coder ids index it directly:
+   * [CAB_GOON] go-on coder, [CAB_CUR0+d] = [depth][CI_CURR_BEST], [CAB_LANE0+k] lane-private trial coders */
+  Cabac cab[1 + (MAXDEPTH + 1) + MAXVC];
   uint8_t ref[264], reff[264];
   uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
   int16_t lane_abs[MAXVC][16];                      /* per-lane |level| list of the coefficient group being coded */
@@ -158,8 +158,14 @@ struct Shared {
   int uni[8];
 };
 
-struct Env { Chain *C; Scratch *G; Shared *S; int cur_ctu, slice_start; };
-FCU_DEV Cabac *slot_ptr(const Env &E, int d, int ci) { return ci == CI_CURR_BEST ? &E.S->cur[d] : &E.G->slots[d][ci]; }
+enum { CAB_GOON = 0, CAB_CUR0 = 1, CAB_LANE0 = 1 + (MAXDEPTH + 1) };
+#ifdef FCU_EMU
+static Shared g_S;
+#else
+__shared__ Shared g_S;
+#endif
+struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
+FCU_DEV Cabac *slot_ptr(const Env E, int d, int ci) { return ci == CI_CURR_BEST ? &g_S.cab[CAB_CUR0 + d] : &E.G->slots[d][ci]; }
 
 /* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
 struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
@@ -221,18 +227,20 @@ FCU_DEV void cab_copy(Cabac *d, const Cabac *s, int lane)     /* cooperative cop
 { const uint32_t *a = (const uint32_t *)s; uint32_t *b = (uint32_t *)d; if (lane < (int)(sizeof(Cabac) / 4)) b[lane] = a[lane]; }
 FCU_DEV void cab_copy1(Cabac *d, const Cabac *s)              /* single-lane copy */
 { const uint32_t *a = (const uint32_t *)s; uint32_t *b = (uint32_t *)d; for (int i = 0; i < (int)(sizeof(Cabac) / 4); i++) b[i] = a[i]; }
-FCU_DEV void cab_bin(Cabac *c, int bin, int ctx)
+/* the hot primitives take the coder id (index into g_S.cab) so that every access is a plain LDS access */
+#define FCU_CB g_S.cab[cid]
+FCU_DEV void cab_bin(int cid, int bin, int ctx)
 {
-  const uint32_t e = g_hot.bin[c->ctx[ctx] * 2 + bin];         /* (bits << 8) | next state */
-  c->bins++;
-  c->frac += (uint64_t)(e >> 8);
-  c->ctx[ctx] = (uint8_t)e;
+  const uint32_t e = g_hot.bin[FCU_CB.ctx[ctx] * 2 + bin];      /* (bits << 8) | next state */
+  FCU_CB.bins++;
+  FCU_CB.frac += (uint64_t)(e >> 8);
+  FCU_CB.ctx[ctx] = (uint8_t)e;
 }
-FCU_DEV void cab_ep(Cabac *c, int n) { c->bins += (uint32_t)n; c->frac += (uint64_t)32768 * (uint64_t)n; }
-FCU_DEV void cab_trm(Cabac *c, int bin) { c->bins++; c->frac += (uint64_t)k_entropy_bits[126 ^ bin]; }
-FCU_DEV void cab_reset_bits(Cabac *c) { c->frac &= 32767; c->bins = 0; }
-FCU_DEV uint32_t cab_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
-FCU_DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return (int)(g_hot.bin[c->ctx[ctx] * 2 + bin] >> 8); }
+FCU_DEV void cab_ep(int cid, int n) { FCU_CB.bins += (uint32_t)n; FCU_CB.frac += (uint64_t)32768 * (uint64_t)n; }
+FCU_DEV void cab_trm(int cid, int bin) { FCU_CB.bins++; FCU_CB.frac += (uint64_t)k_entropy_bits[126 ^ bin]; }
+FCU_DEV void cab_reset_bits(int cid) { FCU_CB.frac &= 32767; FCU_CB.bins = 0; }
+FCU_DEV uint32_t cab_bits(int cid) { return (uint32_t)(FCU_CB.frac >> 15); }
+FCU_DEV int ctx_bits(int cid, int ctx, int bin) { return (int)(g_hot.bin[FCU_CB.ctx[ctx] * 2 + bin] >> 8); }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -276,7 +284,7 @@ FCU_DEV int sig_ctx_inc(int pattern, int first, int pos, int log2, int ch)     /
   }
   return first + offset;
 }
-FCU_DEV void code_coef_remain(Cabac *c, uint32_t symbol, uint32_t rparam)      /* TEncSbac.cpp:338-391 */
+FCU_DEV void code_coef_remain(int c, uint32_t symbol, uint32_t rparam)      /* TEncSbac.cpp:338-391 */
 {
   int code = (int)symbol;
   if (code < (3 << rparam)) { cab_ep(c, (int)(((uint32_t)code >> rparam) + 1)); cab_ep(c, (int)rparam); }
@@ -288,7 +296,7 @@ FCU_DEV void code_coef_remain(Cabac *c, uint32_t symbol, uint32_t rparam)      /
   }
 }
 /* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535 */
-FCU_DEV FCU_NOINLINE void code_coeff_nxn(Cabac *c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   int numSig = 0;
@@ -390,7 +398,7 @@ FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint
   else rate = 0;
   return rate;
 }
-FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
+FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
                              int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, const LevelBits &lb,
                              uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last)
 {                                                          /* xGetCodedLevel, TComTrQuant.cpp:2738-2794 */
@@ -412,7 +420,7 @@ FCU_DEV uint32_t coded_level(const Cabac *c, double lambda, double *codedCost, d
 }
 /* `c` is the coder whose contexts estBit() would snapshot (TEncSbac.cpp:1722-1956); cbfCtx
  * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset). Returns uiAbsSum. */
-FCU_DEV FCU_NOINLINE int rdoq(const Cabac *c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
+FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
                  const Params &P, const RdoqBuf &rb)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
@@ -655,7 +663,7 @@ FCU_DEV int pred_pixel(const uint8_t *ref, int log2, int mode, int isLuma, int d
 }
 
 /* z-scan availability (H.265 6.4.1 == getPULeft/Above/.../BelowLeftAdi, TComDataCU.cpp:1071-1390) */
-FCU_DEV int unit_available(const Env &E, int lx, int ly, int cx, int cy)
+FCU_DEV int unit_available(const Env E, int lx, int ly, int cx, int cy)
 {
   const Params &P = E.C->p;
   if (lx < 0 || ly < 0 || lx >= P.width || ly >= P.height) return 0;
@@ -667,14 +675,13 @@ FCU_DEV int unit_available(const Env &E, int lx, int ly, int cx, int cy)
 }
 
 /* Reference samples of a block (initAdiPatternChType + fillReferenceSamples + smoothing,
- * TComPattern.cpp:104-521) -> S->ref (unfiltered), S->reff (filtered, luma only), S->dc. */
-FCU_DEV FCU_NOINLINE void build_ref(const Env &E, int comp, int px, int py, int log2, int wantFilt)
+ * TComPattern.cpp:104-521) -> g_S.ref (unfiltered), g_S.reff (filtered, luma only), g_S.dc. */
+FCU_DEV FCU_NOINLINE void build_ref(const Env E, int comp, int px, int py, int log2, int wantFilt)
 {
-  Shared *S = E.S;
   const int N = 1 << log2, sh = comp ? 1 : 0, unit = 4 >> sh, total = 4 * N + 1;
   const int lx0 = px << sh, ly0 = py << sh;
   const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
-  uint8_t *ref = S->ref, *avail = (uint8_t *)S->colsum;    /* availability flags staged in colsum (>= 257 bytes) */
+  uint8_t *ref = g_S.ref, *avail = (uint8_t *)g_S.colsum;    /* availability flags staged in colsum (>= 257 bytes) */
   FCU_FOR_LANES {
     for (int i = lane; i < total; i += 64) {
       int a, v = 0;
@@ -692,13 +699,13 @@ FCU_DEV FCU_NOINLINE void build_ref(const Env &E, int comp, int px, int py, int 
         int j = i - 1;
         while (j >= 0 && !avail[j]) j--;
         if (j < 0) { j = i + 1; while (j < total && !avail[j]) j++; }
-        S->reff[i] = (j < total) ? ref[j] : 128;            /* staged in reff, merged below */
+        g_S.reff[i] = (j < total) ? ref[j] : 128;            /* staged in reff, merged below */
       }
     }
   }
-  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) ref[i] = S->reff[i]; }
+  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) ref[i] = g_S.reff[i]; }
   FCU_FOR_LANES {
-    if (lane == 0) { int sum = 0; for (int i = 0; i < N; i++) sum += ref[2 * N + 1 + i] + ref[2 * N - 1 - i]; S->dc = (sum + N) >> (log2 + 1); }
+    if (lane == 0) { int sum = 0; for (int i = 0; i < N; i++) sum += ref[2 * N + 1 + i] + ref[2 * N - 1 - i]; g_S.dc = (sum + N) >> (log2 + 1); }
     if (wantFilt) {
       int strong = 0;
       if (comp == 0 && E.C->p.strong_smoothing && N >= 32) {
@@ -714,7 +721,7 @@ FCU_DEV FCU_NOINLINE void build_ref(const Env &E, int comp, int px, int py, int 
           else if (i == 2 * N) v = tl;
           else { const int k = i - 2 * N; v = ((2 * N - k) * tl + k * tr + N) >> (log2 + 1); }
         } else v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
-        S->reff[i] = (uint8_t)v;
+        g_S.reff[i] = (uint8_t)v;
       }
     }
   }
@@ -748,18 +755,18 @@ FCU_DEV int32_t dequant1(int q, int log2, int qp)          /* xDeQuant flat, TCo
 /* neighbour decisions (MPM, split context)                                                  */
 /* ======================================================================================== */
 FCU_DEV int inside_cu(const CuObj *cu, int lx, int ly) { const int s = CTU >> cu->depth_cu; return lx >= cu->x && lx < cu->x + s && ly >= cu->y && ly < cu->y + s; }
-FCU_DEV int nb_depth(const Env &E, const CuObj *cu, int lx, int ly)
+FCU_DEV int nb_depth(const Env E, const CuObj *cu, int lx, int ly)
 { return inside_cu(cu, lx, ly) ? cu->depth[zidx_of(lx, ly) - cu->zidx] : E.C->out[(ly >> 6) * E.C->w_ctu + (lx >> 6)].depth[zidx_of(lx, ly)]; }
-FCU_DEV int nb_luma_dir(const Env &E, const CuObj *cu, int lx, int ly)
+FCU_DEV int nb_luma_dir(const Env E, const CuObj *cu, int lx, int ly)
 {
   if (inside_cu(cu, lx, ly)) { const int p = zidx_of(lx, ly) - cu->zidx; return cu->pred_mode[p] == MODE_INTRA ? cu->intra_dir[0][p] : DC; }
   const fcu_ctu_out *c = &E.C->out[(ly >> 6) * E.C->w_ctu + (lx >> 6)]; const int p = zidx_of(lx, ly);
   return c->pred_mode[p] == MODE_INTRA ? c->intra_dir[0][p] : DC;
 }
-FCU_DEV int left_ctu_ok(const Env &E, int lx, int ly) { if (lx == 0) return 0; if (lx & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - 1 >= E.slice_start; }
-FCU_DEV int above_ctu_ok(const Env &E, int lx, int ly) { if (ly == 0) return 0; if (ly & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - E.C->w_ctu >= E.slice_start; }
+FCU_DEV int left_ctu_ok(const Env E, int lx, int ly) { if (lx == 0) return 0; if (lx & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - 1 >= E.slice_start; }
+FCU_DEV int above_ctu_ok(const Env E, int lx, int ly) { if (ly == 0) return 0; if (ly & 63) return 1; return (ly >> 6) * E.C->w_ctu + (lx >> 6) - E.C->w_ctu >= E.slice_start; }
 /* getIntraDirPredictor, TComDataCU.cpp:1542-1624 */
-FCU_DEV int intra_dir_predictor(const Env &E, const CuObj *cu, int part, int *preds)
+FCU_DEV int intra_dir_predictor(const Env E, const CuObj *cu, int part, int *preds)
 {
   const int z = cu->zidx + part, lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
   const int left = left_ctu_ok(E, lx, ly) ? nb_luma_dir(E, cu, lx - 1, ly) : DC;
@@ -782,7 +789,7 @@ FCU_DEV int min_tu_log2_in_cu(int depth, int partSize)      /* getQuadtreeTULog2
 }
 
 /* ---- syntax element coders (serial, any Cabac) ------------------------------------------ */
-FCU_DEV void code_split_flag(const Env &E, Cabac *c, const CuObj *cu, int part, int depth)   /* TEncSbac.cpp:613-628 */
+FCU_DEV void code_split_flag(const Env E, int c, const CuObj *cu, int part, int depth)   /* TEncSbac.cpp:613-628 */
 {
   if (depth == MAXDEPTH) return;
   const int z = cu->zidx + part, lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
@@ -792,14 +799,14 @@ FCU_DEV void code_split_flag(const Env &E, Cabac *c, const CuObj *cu, int part, 
   cab_bin(c, cu->depth[part] > depth, CTX_SPLIT + ctx);
 }
 /* codeIntraDirLumaAng for one PU with known MPM list (TEncSbac.cpp:643-696) */
-FCU_DEV void code_luma_dir_bits(Cabac *c, int dir, const int *preds)
+FCU_DEV void code_luma_dir_bits(int c, int dir, const int *preds)
 {
   int predIdx = -1;
   for (int i = 0; i < 3; i++) if (dir == preds[i]) predIdx = i;
   cab_bin(c, predIdx != -1, CTX_INTRA_LUMA);
   cab_ep(c, predIdx != -1 ? (predIdx ? 2 : 1) : 5);
 }
-FCU_DEV FCU_NOINLINE void code_intra_dir_luma(const Env &E, Cabac *c, const CuObj *cu, int part, int multiple)
+FCU_DEV FCU_NOINLINE void code_intra_dir_luma(const Env E, int c, const CuObj *cu, int part, int multiple)
 {
   int preds[4][3], predIdx[4];
   const int partNum = multiple ? (cu->part_size[part] == SIZE_NxN ? 4 : 1) : 1;
@@ -813,17 +820,17 @@ FCU_DEV FCU_NOINLINE void code_intra_dir_luma(const Env &E, Cabac *c, const CuOb
   }
   for (int j = 0; j < partNum; j++) cab_ep(c, predIdx[j] != -1 ? (predIdx[j] ? 2 : 1) : 5);
 }
-FCU_DEV void code_intra_dir_chroma(Cabac *c, int dir)       /* TEncSbac.cpp:698-725 */
+FCU_DEV void code_intra_dir_chroma(int c, int dir)       /* TEncSbac.cpp:698-725 */
 { if (dir == DM_CHROMA) cab_bin(c, 0, CTX_CHROMA_PRED); else { cab_bin(c, 1, CTX_CHROMA_PRED); cab_ep(c, 2); } }
 FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
 
 /* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
-FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env E, int c, const CuObj *cu, const TU root, int bLuma, int bChroma)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
-    const TU &tu = st[sp];
+    const TU tu = st[sp];
     if (ci[sp] < 0) {
       const int subdiv = cu->tr_idx[tu.part] > tu.tr_depth;
       if (cu->part_size[0] == SIZE_NxN && tu.tr_depth == 0) { }
@@ -845,12 +852,12 @@ FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env &E, Cabac *c, const CuObj 
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &root, int comp, int realCoeff)
+FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env E, int c, const CuObj *cu, const TU root, int comp, int realCoeff)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
-    const TU &tu = st[sp];
+    const TU tu = st[sp];
     if (ci[sp] < 0) {
       if (!(cu->tr_idx[tu.part] > tu.tr_depth)) {
         if (!(comp && tu.cw == 0) && ((cu->cbf[comp][tu.part] >> tu.tr_depth) & 1)) {
@@ -858,7 +865,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, 
           const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
-          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, E.S->lane_abs[0]);
+          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -868,7 +875,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env &E, Cabac *c, const CuObj *cu, 
     { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
   }
 }
-FCU_DEV void enc_intra_header(const Env &E, Cabac *c, const CuObj *cu, int trDepth, int part, int bLuma, int bChroma)
+FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, int part, int bLuma, int bChroma)
 {
   if (bLuma) {
     if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, cu->part_size[0] == SIZE_2Nx2N, CTX_PARTSIZE);
@@ -877,7 +884,7 @@ FCU_DEV void enc_intra_header(const Env &E, Cabac *c, const CuObj *cu, int trDep
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
-FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj *cu, const TU &tu, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env E, int c, const CuObj *cu, const TU tu, int bLuma, int bChroma)
 {
   cab_reset_bits(c);
   enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
@@ -888,12 +895,12 @@ FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env &E, Cabac *c, const CuObj 
 }
 
 /* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
-FCU_DEV FCU_NOINLINE void encode_transform(const Env &E, Cabac *c, const CuObj *cu, int cuPart, const TU &root)
+FCU_DEV FCU_NOINLINE void encode_transform(const Env E, int c, const CuObj *cu, int cuPart, const TU root)
 {
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
-    const TU &tu = st[sp];
+    const TU tu = st[sp];
     if (ci[sp] < 0) {
       const int part = cuPart + tu.part, trIdx = tu.tr_depth, subdiv = cu->tr_idx[part] > trIdx;
       if (cu->part_size[part] == SIZE_NxN && trIdx == 0) { }
@@ -916,7 +923,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(const Env &E, Cabac *c, const CuObj *
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
           const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
-          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, E.S->lane_abs[0]);
+          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -926,7 +933,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(const Env &E, Cabac *c, const CuObj *
     { TU ch; tu_child(ch, st[sp], ci[sp], 1); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
   }
 }
-FCU_DEV void encode_cu_syntax(const Env &E, Cabac *c, const CuObj *cu, int cuPart, int depth)   /* TEncCu.cpp:2117-2141 / 1753-1778 */
+FCU_DEV void encode_cu_syntax(const Env E, int c, const CuObj *cu, int cuPart, int depth)   /* TEncCu.cpp:2117-2141 / 1753-1778 */
 {
   if (depth == MAXDEPTH) cab_bin(c, cu->part_size[cuPart] == SIZE_2Nx2N, CTX_PARTSIZE);
   code_intra_dir_luma(E, c, cu, cuPart, 1);
@@ -938,7 +945,7 @@ FCU_DEV void encode_cu_syntax(const Env &E, Cabac *c, const CuObj *cu, int cuPar
 /* ======================================================================================== */
 /* CU object helpers (cooperative)                                                           */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void cu_init(const Env &E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
+FCU_DEV FCU_NOINLINE void cu_init(const Env E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
 {
   const int n = NPART >> (2 * depth), s = CTU >> depth;
   FCU_FOR_LANES {
@@ -953,7 +960,7 @@ FCU_DEV FCU_NOINLINE void cu_init(const Env &E, CuObj *cu, int depth, int x, int
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env &E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
+FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
 {
   const int n = src->nparts, off = partUnitIdx * n;
   FCU_FOR_LANES {
@@ -969,7 +976,7 @@ FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env &E, CuObj *dst, const CuOb
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env &E, const CuObj *cu)                             /* copyToPic */
+FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env E, const CuObj *cu)                             /* copyToPic */
 {
   fcu_ctu_out *p = &E.C->out[E.cur_ctu];
   const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
@@ -986,7 +993,7 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env &E, const CuObj *cu)         
     for (int i = lane; i < n * 4; i += 64) { p->coeff_cb[off * 4 + i] = cu->coef[1][i]; p->coeff_cr[off * 4 + i] = cu->coef[2][i]; }
   }
 }
-FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env &E, const Yuv *r, int x, int y, int s)
+FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env E, const Yuv *r, int x, int y, int s)
 {
   FCU_FOR_LANES {
     for (int c = 0; c < 3; c++) {
@@ -1002,10 +1009,10 @@ FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env &E, const Yuv *r, int x, in
 /* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
 /* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int comp, Cabac *cab, int save1load2)
+FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp, int cab, int save1load2)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
-  if (comp && tu.cw == 0) { FCU_SERIAL { S->t_dist = 0; S->t_abs = 0; } return; }
+  Scratch *G = E.G; const Params &P = E.C->p;
+  if (comp && tu.cw == 0) { FCU_SERIAL { g_S.t_dist = 0; g_S.t_abs = 0; } return; }
   const int d = cu->depth_cu, N = comp ? tu.cw : (1 << tu.log2), log2 = ilog2(N), n2 = N * N;
   const int bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y, bs = comp ? 32 : 64, sh = comp ? 1 : 0;
   const int part = tu.part, layer = LOG2_MAXTU - tu.log2;
@@ -1024,7 +1031,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int co
     const int filt = use_filtered_ref(mode, log2, comp == 0);
     build_ref(E, comp, px, py, log2, filt);
     FCU_FOR_LANES {
-      const uint8_t *r = filt ? S->reff : S->ref; const int dc = S->dc;
+      const uint8_t *r = filt ? g_S.reff : g_S.ref; const int dc = g_S.dc;
       for (int i = lane; i < n2; i += 64) {
         const int y = i >> log2, x = i & (N - 1);
         const int v = pred_pixel(r, log2, mode, comp == 0, dc, x, y);
@@ -1052,12 +1059,12 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int co
       FCU_TIC(t8_);
       RdoqBuf rb = { G->r_cc, G->r_cs, G->r_c0, G->r_up, G->r_dn, G->r_sd, G->r_du, G->r_cg };
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      S->t_abs = rdoq(cab, G->p_tcoef, G->p_qcoef, log2, comp, coef_scan_idx(mode, log2, comp), cbfCtx, P, rb);
+      g_S.t_abs = rdoq(cab, G->p_tcoef, G->p_qcoef, log2, comp, coef_scan_idx(mode, log2, comp), cbfCtx, P, rb);
       E.C->n_tu_trials++;
       FCU_TOC(E, t8_, 8);
     }
   }
-  const int absSum = S->t_abs;
+  const int absSum = g_S.t_abs;
   FCU_FOR_LANES {                                            /* setCbfPartRange + coefficient store */
     const int np = comp ? tu_nparts_c(tu) : tu.nparts;
     for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
@@ -1071,7 +1078,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int co
     }
   }
   FCU_FOR_LANES {
-    if (lane == 0) S->sad[35] = 0;
+    if (lane == 0) g_S.sad[35] = 0;
   }
   FCU_FOR_LANES {
     uint32_t sse = 0;
@@ -1081,13 +1088,13 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env &E, CuObj *cu, const TU &tu, int co
       pred[y * bs + x] = (uint8_t)r; recqt[y * bs + x] = (uint8_t)r; recpic[y * rs + x] = (uint8_t)r;
       const int e = org[y * bs + x] - r; sse += (uint32_t)(e * e);
     }
-    FCU_ATOMIC_ADD(&S->sad[35], sse);
+    FCU_ATOMIC_ADD(&g_S.sad[35], sse);
   }
-  FCU_SERIAL { const uint32_t sse = S->sad[35]; S->t_dist = comp ? (uint32_t)(P.chroma_weight * (double)sse) : sse; }
+  FCU_SERIAL { const uint32_t sse = g_S.sad[35]; g_S.t_dist = comp ? (uint32_t)(P.chroma_weight * (double)sse) : sse; }
 }
 
 /* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
-FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env &E, const TU &tu, int comp)
+FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env E, const TU tu, int comp)
 {
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
@@ -1096,7 +1103,7 @@ FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env &E, const TU &tu, int 
   const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
   FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
 }
-FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env &E, const CuObj *cu, const TU &tu, int comp)
+FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env E, const CuObj *cu, const TU tu, int comp)
 {
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
@@ -1109,12 +1116,12 @@ FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env &E, const CuObj *cu, co
 
 /* ======================================================================================== */
 /* xRecurIntraCodingLumaQT (sequential path), TEncSearch.cpp:1393-1713                        */
-/* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to S->q_dist/q_cost[LEVEL].   */
+/* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to g_S.q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, int checkFirst, int reuseVc = -1)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int checkFirst, int reuseVc = -1)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
   const int partSize = cu->part_size[part];
   const int checkFull = log2 <= LOG2_MAXTU;
@@ -1126,75 +1133,75 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
 
   if (checkFull) {
     if (checkTS) {
-      FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
+      FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
       for (int modeId = 0; modeId < 2; modeId++) {
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)modeId; }
-        tu_trial(E, cu, tu, 0, &S->goon, modeId == 0 ? 1 : 2);
-        const uint32_t tmpDist = S->t_dist, tmpCbf = (cu->cbf[0][part] >> trDepth) & 1;
+        tu_trial(E, cu, tu, 0, (CAB_GOON), modeId == 0 ? 1 : 2);
+        const uint32_t tmpDist = g_S.t_dist, tmpCbf = (cu->cbf[0][part] >> trDepth) & 1;
         double tmpCost;
         if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
         else {
-          FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
-          tmpCost = rd_cost(P, S->vc_bits[0], tmpDist);
+          FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+          tmpCost = rd_cost(P, g_S.vc_bits[0], tmpDist);
         }
         if (tmpCost < singleCost) {
           singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
-          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &S->goon, lane); }
+          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
         }
-        if (modeId == 0) FCU_FOR_LANES cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
+        if (modeId == 0) FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)bestModeId; }
       if (bestModeId == 0) {
         load_intra_result_qt(E, cu, tu, 0);
-        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_TEMP_BEST), lane); }
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_TEMP_BEST), lane); }
       }
     } else {
-      if (checkSplit) FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
+      if (checkSplit) FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = 0; }
       if (reuseVc >= 0) {
         /* the un-split trial of the re-run (TEncSearch.cpp:2518-2586) repeats the first-pass trial of the same mode
          * from the same snapshot: take its levels, reconstruction, distortion, bits and coder state instead of
          * recomputing them (the candidate pools still hold them) */
-        const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = S->vc_abs[bv] > 0;
+        const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = g_S.vc_abs[bv] > 0;
         FCU_FOR_LANES {
           for (int i = lane; i < n2; i += 64) {
             G->qt_coef[0][layer][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
             G->qt_rec[layer].y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
           }
           for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
-          cab_copy(&S->goon, &S->lane[bv], lane);
+          cab_copy(&g_S.cab[CAB_GOON], &g_S.cab[CAB_LANE0 + bv], lane);
         }
-        singleDist = S->vc_dist[bv]; singleCbf = (uint32_t)cbf; singleCost = S->vc_cost[bv];
+        singleDist = g_S.vc_dist[bv]; singleCbf = (uint32_t)cbf; singleCost = g_S.vc_cost[bv];
       } else {
-        tu_trial(E, cu, tu, 0, &S->goon, 0);
-        singleDist = S->t_dist;
+        tu_trial(E, cu, tu, 0, (CAB_GOON), 0);
+        singleDist = g_S.t_dist;
         if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
-        FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
-        singleCost = rd_cost(P, S->vc_bits[0], singleDist);
+        FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+        singleCost = rd_cost(P, g_S.vc_bits[0], singleDist);
       }
     }
   }
   if (checkSplit) {
     if constexpr (LEVEL < 3) {
-      if (checkFull) { FCU_FOR_LANES { cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), &S->goon, lane); } FCU_FOR_LANES { cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane); } }
-      else FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &S->goon, lane);
-      FCU_SERIAL { S->q_dist[LEVEL + 1] = 0; S->q_cost[LEVEL + 1] = 0; }
+      if (checkFull) { FCU_FOR_LANES { cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), &g_S.cab[CAB_GOON], lane); } FCU_FOR_LANES { cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane); } }
+      else FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
+      FCU_SERIAL { g_S.q_dist[LEVEL + 1] = 0; g_S.q_cost[LEVEL + 1] = 0; }
       uint32_t splitCbf = 0;
       for (int i = 0; i < 4; i++) {
         TU c; tu_child(c, tu, i, 0);
         recur_luma_qt<LEVEL + 1>(E, cu, c, checkFirst);
         splitCbf |= (cu->cbf[0][c.part] >> c.tr_depth) & 1;
       }
-      const uint32_t splitDist = S->q_dist[LEVEL + 1];
+      const uint32_t splitDist = g_S.q_dist[LEVEL + 1];
       FCU_FOR_LANES {
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
-        cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
+        cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
-      FCU_SERIAL { S->vc_bits[0] = intra_bits_qt(E, &S->goon, cu, tu, 1, 0); }
-      const double splitCost = rd_cost(P, S->vc_bits[0], splitDist);
-      if (splitCost < singleCost) { FCU_SERIAL { S->q_dist[LEVEL] += splitDist; S->q_cost[LEVEL] += splitCost; } return; }
+      FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+      const double splitCost = rd_cost(P, g_S.vc_bits[0], splitDist);
+      if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; } return; }
       FCU_FOR_LANES {
-        cab_copy(&S->goon, slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), lane);
+        cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), lane);
         for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cu->tskip[0][part + i] = (uint8_t)bestModeId; }
         const int N = 1 << log2, layer = LOG2_MAXTU - log2;
         const uint8_t *s = G->qt_rec[layer].y + tu.y * 64 + tu.x;
@@ -1203,11 +1210,11 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env &E, CuObj *cu, const TU &tu, i
       }
     }
   }
-  FCU_SERIAL { S->q_dist[LEVEL] += singleDist; S->q_cost[LEVEL] += singleCost; }
+  FCU_SERIAL { g_S.q_dist[LEVEL] += singleDist; g_S.q_cost[LEVEL] += singleCost; }
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
-FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env &E, CuObj *cu, const TU &root, Yuv *reco)
+FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env E, CuObj *cu, const TU root, Yuv *reco)
 {
   Scratch *G = E.G;
   TU st[4]; int ci[4]; int sp = 0;
@@ -1237,29 +1244,29 @@ FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env &E, CuObj *cu, cons
 /* RMD: 35 predictions + Hadamard SATD staged through LDS (TEncSearch.cpp:2300-2361,          */
 /* TComRdCost.cpp:1343-1604) and the sorted candidate list (xUpdateCandList :5345-5370)       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV FCU_NOINLINE void rmd(const Env E, CuObj *cu, const TU tu)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
   build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   const int usz = N >= 8 ? 8 : 4, ul = usz == 8 ? 3 : 2, upix = usz * usz, bpr = N / usz, nblk = bpr * bpr;
   const int totalUnits = 35 * nblk, K = (DIFFN / upix) < (128 / usz) ? (DIFFN / upix) : (128 / usz);
-  FCU_FOR_LANES { if (lane < 36) S->sad[lane] = 0; }
+  FCU_FOR_LANES { if (lane < 36) g_S.sad[lane] = 0; }
   for (int u0 = 0; u0 < totalUnits; u0 += K) {
     const int nu = (totalUnits - u0) < K ? (totalUnits - u0) : K;
     FCU_FOR_LANES {                                          /* residual of unit u = (mode, block) */
-      const int dc = S->dc;
+      const int dc = g_S.dc;
       for (int i = lane; i < nu * upix; i += 64) {
         const int u = u0 + (i >> (2 * ul)), p = i & (upix - 1), mode = u / nblk, blk = u % nblk;
         const int x = (blk % bpr) * usz + (p & (usz - 1)), y = (blk / bpr) * usz + (p >> ul);
-        const uint8_t *r = use_filtered_ref(mode, log2, 1) ? S->reff : S->ref;
-        S->diff[i] = (int16_t)(org[y * 64 + x] - pred_pixel(r, log2, mode, 1, dc, x, y));
+        const uint8_t *r = use_filtered_ref(mode, log2, 1) ? g_S.reff : g_S.ref;
+        g_S.diff[i] = (int16_t)(org[y * 64 + x] - pred_pixel(r, log2, mode, 1, dc, x, y));
       }
     }
     FCU_FOR_LANES {                                          /* rows */
       for (int it = lane; it < nu * usz; it += 64) {
-        int16_t *row = S->diff + it * usz; int v[8];
+        int16_t *row = g_S.diff + it * usz; int v[8];
         for (int k = 0; k < usz; k++) v[k] = row[k];
         for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
         for (int k = 0; k < usz; k++) row[k] = (int16_t)v[k];
@@ -1267,18 +1274,18 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
     }
     FCU_FOR_LANES {                                          /* columns + abs sum */
       for (int it = lane; it < nu * usz; it += 64) {
-        const int16_t *col = S->diff + (it >> ul) * upix + (it & (usz - 1)); int v[8];
+        const int16_t *col = g_S.diff + (it >> ul) * upix + (it & (usz - 1)); int v[8];
         for (int k = 0; k < usz; k++) v[k] = col[k * usz];
         for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
         int s = 0; for (int k = 0; k < usz; k++) s += iabs(v[k]);
-        S->colsum[it] = s;
+        g_S.colsum[it] = s;
       }
     }
     FCU_FOR_LANES {
       for (int uu = lane; uu < nu; uu += 64) {
-        int s = 0; for (int k = 0; k < usz; k++) s += S->colsum[uu * usz + k];
+        int s = 0; for (int k = 0; k < usz; k++) s += g_S.colsum[uu * usz + k];
         const uint32_t v = (uint32_t)(usz == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
-        FCU_ATOMIC_ADD(&S->sad[(u0 + uu) / nblk], v);
+        FCU_ATOMIC_ADD(&g_S.sad[(u0 + uu) / nblk], v);
       }
     }
   }
@@ -1286,7 +1293,7 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
   FCU_SERIAL {
     int preds[3];
     const int nm = intra_dir_predictor(E, cu, tu.part, preds);
-    S->preds[0] = preds[0]; S->preds[1] = preds[1]; S->preds[2] = preds[2]; S->n_mpm = nm;
+    g_S.preds[0] = preds[0]; g_S.preds[1] = preds[1]; g_S.preds[2] = preds[2]; g_S.n_mpm = nm;
     const Cabac *cb = slot_ptr(E, d, CI_CURR_BEST);
     const uint64_t carry = cb->frac & 32767;               /* loadIntraDirMode + resetBits, TEncSearch.cpp:5313-5340 */
     int numFull = k_rd_mode_num[log2 - 2];
@@ -1295,22 +1302,22 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
     for (int mode = 0; mode < 35; mode++) {
       int predIdx = -1;
       for (int i = 0; i < 3; i++) if (mode == preds[i]) predIdx = i;
-      const uint64_t fr = carry + (uint64_t)ctx_bits(cb, CTX_INTRA_LUMA, predIdx != -1) + (uint64_t)32768 * (uint64_t)(predIdx != -1 ? (predIdx ? 2 : 1) : 5);
+      const uint64_t fr = carry + (uint64_t)ctx_bits(CAB_CUR0 + d, CTX_INTRA_LUMA, predIdx != -1) + (uint64_t)32768 * (uint64_t)(predIdx != -1 ? (predIdx ? 2 : 1) : 5);
       const uint32_t modeBits = (uint32_t)(fr >> 15);
-      const double cost = (double)S->sad[mode] + (double)modeBits * P.sqrt_lambda;
+      const double cost = (double)g_S.sad[mode] + (double)modeBits * P.sqrt_lambda;
       int shift = 0;
       while (shift < numFull && cost < candCost[numFull - 1 - shift]) shift++;
       if (shift != 0) {
-        for (int i = 1; i < shift; i++) { S->rd_mode[numFull - i] = S->rd_mode[numFull - 1 - i]; candCost[numFull - i] = candCost[numFull - 1 - i]; }
-        S->rd_mode[numFull - shift] = mode; candCost[numFull - shift] = cost;
+        for (int i = 1; i < shift; i++) { g_S.rd_mode[numFull - i] = g_S.rd_mode[numFull - 1 - i]; candCost[numFull - i] = candCost[numFull - 1 - i]; }
+        g_S.rd_mode[numFull - shift] = mode; candCost[numFull - shift] = cost;
       }
     }
     for (int j = 0; j < nm; j++) {
       int inc = 0;
-      for (int i = 0; i < numFull; i++) inc |= (preds[j] == S->rd_mode[i]);
-      if (!inc) S->rd_mode[numFull++] = preds[j];
+      for (int i = 0; i < numFull; i++) inc |= (preds[j] == g_S.rd_mode[i]);
+      if (!inc) g_S.rd_mode[numFull++] = preds[j];
     }
-    S->n_rd = numFull;
+    g_S.n_rd = numFull;
   }
 }
 
@@ -1319,23 +1326,23 @@ FCU_DEV FCU_NOINLINE void rmd(const Env &E, CuObj *cu, const TU &tu)
 /* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
 /* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const TU &tu)
+FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU tu)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
   const int partSize = cu->part_size[part];
   int checkTS = P.transform_skip && log2 == 2;
   if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
-  const int nc = S->n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
+  const int nc = g_S.n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
   const int useDst = log2 == 2;
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   /* reference samples are shared by all candidates: the TU is the whole PU */
   build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   FCU_FOR_LANES {                                            /* prediction + residual per candidate */
-    const int dc = S->dc;
+    const int dc = g_S.dc;
     for (int i = lane; i < nc * n2; i += 64) {
-      const int cnd = i / n2, p = i - cnd * n2, y = p >> log2, x = p & (N - 1), mode = S->rd_mode[cnd];
-      const uint8_t *r = use_filtered_ref(mode, log2, 1) ? S->reff : S->ref;
+      const int cnd = i / n2, p = i - cnd * n2, y = p >> log2, x = p & (N - 1), mode = g_S.rd_mode[cnd];
+      const uint8_t *r = use_filtered_ref(mode, log2, 1) ? g_S.reff : g_S.ref;
       const int v = pred_pixel(r, log2, mode, 1, dc, x, y);
       G->p_pred[i] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * 64 + x] - v);
     }
@@ -1350,16 +1357,16 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
   FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
     if (lane < nvc) {
-      const int mode = S->rd_mode[lane / tsv];
+      const int mode = g_S.rd_mode[lane / tsv];
       RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      S->vc_abs[lane] = rdoq(slot_ptr(E, d, CI_CURR_BEST), G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
-      S->vc_dist[lane] = 0;
+      g_S.vc_abs[lane] = rdoq(CAB_CUR0 + d, G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
+      g_S.vc_dist[lane] = 0;
     }
     if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
   }
   FCU_TOC(E, t2_, 2);
-  FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = S->vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp) : 0; } }
+  FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = g_S.vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp) : 0; } }
   FCU_FOR_LANES {
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2, ts = v % tsv;
@@ -1371,48 +1378,48 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
       int res = 0;
-      if (S->vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, useDst, p);
+      if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, useDst, p);
       const int r = clip8(G->p_pred[cnd * n2 + p] + res);
       G->p_rec[i] = (uint8_t)r;
       const int e = org[y * 64 + x] - r;
-      FCU_ATOMIC_ADD(&S->vc_dist[v], (uint32_t)(e * e));
+      FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
     }
   }
   FCU_TIC(t3_);
   FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
     if (lane < nvc) {
-      const int cnd = lane / tsv, ts = lane % tsv, mode = S->rd_mode[cnd], cbf = S->vc_abs[lane] > 0;
+      const int cnd = lane / tsv, ts = lane % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[lane] > 0;
       double cost;
       if (ts && !cbf) cost = FCU_MAX_DOUBLE;                 /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
       else {
-        Cabac *c = &S->lane[lane];
-        cab_copy1(c, slot_ptr(E, d, CI_CURR_BEST));
+        const int c = CAB_LANE0 + lane;
+        cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
         cab_reset_bits(c);
         if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
-        code_luma_dir_bits(c, mode, S->preds);
+        code_luma_dir_bits(c, mode, g_S.preds);
         if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
           cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P, S->lane_abs[lane]);
-        S->vc_bits[lane] = cab_bits(c);
-        cost = rd_cost(P, S->vc_bits[lane], S->vc_dist[lane]);
+        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
+        g_S.vc_bits[lane] = cab_bits(c);
+        cost = rd_cost(P, g_S.vc_bits[lane], g_S.vc_dist[lane]);
       }
-      S->vc_cost[lane] = cost;
+      g_S.vc_cost[lane] = cost;
     }
   }
   FCU_TOC(E, t3_, 3);
   FCU_SERIAL {                                               /* strict '<', earlier candidate wins ties */
     double best = FCU_MAX_DOUBLE; int bv = 0;
     for (int cnd = 0; cnd < nc; cnd++) {
-      int v = cnd * tsv; double c = S->vc_cost[v];
-      if (tsv == 2 && S->vc_cost[v + 1] < c) { v = v + 1; c = S->vc_cost[v]; }
+      int v = cnd * tsv; double c = g_S.vc_cost[v];
+      if (tsv == 2 && g_S.vc_cost[v + 1] < c) { v = v + 1; c = g_S.vc_cost[v]; }
       if (c < best) { best = c; bv = v; }
     }
-    S->pu_best_vc = bv; S->pu_best_cost = best; S->pu_best_dist = S->vc_dist[bv]; S->pu_best_mode = S->rd_mode[bv / tsv];
+    g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
   }
   {                                                          /* xSetIntraResultLumaQT + decision snapshot */
-    const int bv = S->pu_best_vc, ts = bv % tsv, cbf = S->vc_abs[bv] > 0;
-    Yuv *reco = &G->reco[d][1 - S->reco_best_idx[d]];
+    const int bv = g_S.pu_best_vc, ts = bv % tsv, cbf = g_S.vc_abs[bv] > 0;
+    Yuv *reco = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES {
       for (int i = lane; i < n2; i += 64) {
         cu->coef[0][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
@@ -1426,14 +1433,14 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env &E, CuObj *cu, const T
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env E, CuObj *cu)
 {
-  Shared *S = E.S; Scratch *G = E.G;
+  Scratch *G = E.G;
   const int d = cu->depth_cu, partSize = cu->part_size[0];
   const int initTrDepth = partSize == SIZE_2Nx2N ? 0 : 1, numPU = 1 << (2 * initTrDepth), qNumParts = cu->nparts >> 2;
   uint32_t overallDistY = 0;
   TU root; tu_root(root, d);
-  Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+  Yuv *recoT = &G->reco[d][1 - g_S.reco_best_idx[d]];
   for (int pu = 0; pu < numPU; pu++) {
     TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
@@ -1441,14 +1448,14 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
     if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(E, cu, tu); FCU_TOC(E, t_, 1); }
     else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
-      FCU_SERIAL { S->pu_best_cost = FCU_MAX_DOUBLE; S->pu_best_mode = 0; S->pu_best_dist = 0; }
-      const int nc = S->n_rd;
+      FCU_SERIAL { g_S.pu_best_cost = FCU_MAX_DOUBLE; g_S.pu_best_mode = 0; g_S.pu_best_dist = 0; }
+      const int nc = g_S.n_rd;
       for (int m = 0; m < nc; m++) {
-        const int orgMode = S->rd_mode[m];
-        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
+        const int orgMode = g_S.rd_mode[m];
+        FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
         recur_luma_qt<0>(E, cu, tu, 1);
-        if (S->q_cost[0] < S->pu_best_cost) {
-          FCU_SERIAL { S->pu_best_mode = orgMode; S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
+        if (g_S.q_cost[0] < g_S.pu_best_cost) {
+          FCU_SERIAL { g_S.pu_best_mode = orgMode; g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
           set_intra_result_luma_qt(E, cu, tu, recoT);
           FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
         }
@@ -1458,17 +1465,17 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
      * re-run reproduces the first-pass trial exactly (same snapshot, same inputs) and `<` keeps the
      * earlier result, so it is skipped. */
     if (log2 > min_tu_log2_in_cu(d, partSize)) {
-      const int orgMode = S->pu_best_mode;
-      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { S->q_dist[0] = 0; S->q_cost[0] = 0; } }
-      { FCU_TIC(t_); recur_luma_qt<0>(E, cu, tu, 0, singleTU ? S->pu_best_vc : -1); FCU_TOC(E, t_, 4); }
-      if (S->q_cost[0] < S->pu_best_cost) {
-        FCU_SERIAL { S->pu_best_dist = S->q_dist[0]; S->pu_best_cost = S->q_cost[0]; }
+      const int orgMode = g_S.pu_best_mode;
+      FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
+      { FCU_TIC(t_); recur_luma_qt<0>(E, cu, tu, 0, singleTU ? g_S.pu_best_vc : -1); FCU_TOC(E, t_, 4); }
+      if (g_S.q_cost[0] < g_S.pu_best_cost) {
+        FCU_SERIAL { g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
         set_intra_result_luma_qt(E, cu, tu, recoT);
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
       }
     }
-    overallDistY += S->pu_best_dist;
-    const int bestMode = S->pu_best_mode;
+    overallDistY += g_S.pu_best_dist;
+    const int bestMode = g_S.pu_best_mode;
     FCU_FOR_LANES {
       for (int i = lane; i < tu.nparts; i += 64) {
         cu->tr_idx[partOffset + i] = G->tmp_tr_idx[i]; cu->cbf[0][partOffset + i] = G->tmp_cbf[i]; cu->tskip[0][partOffset + i] = G->tmp_tskip[i];
@@ -1487,7 +1494,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
       for (int o = 0; o < 4 * qNumParts; o++) { cu->cbf[0][o] |= cy; cu->cbf[1][o] |= cu1; cu->cbf[2][o] |= cv; }
     }
   }
-  FCU_FOR_LANES { cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) cu->dist = overallDistY; }
+  FCU_FOR_LANES { cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) cu->dist = overallDistY; }
 }
 
 /* ======================================================================================== */
@@ -1498,15 +1505,15 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env &E, CuObj *cu)
 /* transform / reconstruction for all modes, RDOQ and bit counting one mode (x transform-skip   */
 /* variant) per lane on lane-private coders.                                                   */
 /* ======================================================================================== */
-FCU_DEV void chroma_leaf_refs5(const Env &E, const CuObj *cu, int comp, int px, int py, int log2)
+FCU_DEV void chroma_leaf_refs5(const Env E, const CuObj *cu, int comp, int px, int py, int log2)
 {
   /* reference samples of one chroma block for the five modes: outside the CU from the picture, inside from
    * the mode's own overlay (what PicYuvRec would hold during that mode's trial, TEncSearch.cpp:1374) */
-  Shared *S = E.S; Scratch *G = E.G;
+  Scratch *G = E.G;
   const int N = 1 << log2, total = 4 * N + 1, lx0 = px << 1, ly0 = py << 1;
   const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
   const int cx0 = cu->x >> 1, cy0 = cu->y >> 1, cs = (CTU >> cu->depth_cu) >> 1;
-  uint8_t *avail = (uint8_t *)S->colsum;
+  uint8_t *avail = (uint8_t *)g_S.colsum;
   FCU_FOR_LANES {
     for (int i = lane; i < total; i += 64) {
       int a, x, y;
@@ -1518,7 +1525,7 @@ FCU_DEV void chroma_leaf_refs5(const Env &E, const CuObj *cu, int comp, int px, 
         const int inside = x >= cx0 && x < cx0 + cs && y >= cy0 && y < cy0 + cs;
         for (int m = 0; m < 5; m++) {
           const uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
-          S->ref5[m][i] = inside ? ov[(y - cy0) * 32 + (x - cx0)] : rec[y * stride + x];
+          g_S.ref5[m][i] = inside ? ov[(y - cy0) * 32 + (x - cx0)] : rec[y * stride + x];
         }
       }
     }
@@ -1529,16 +1536,16 @@ FCU_DEV void chroma_leaf_refs5(const Env &E, const CuObj *cu, int comp, int px, 
         int j = i - 1;
         while (j >= 0 && !avail[j]) j--;
         if (j < 0) { j = i + 1; while (j < total && !avail[j]) j++; }
-        for (int m = 0; m < 5; m++) S->ref5b[m][i] = (j < total) ? S->ref5[m][j] : 128;
+        for (int m = 0; m < 5; m++) g_S.ref5b[m][i] = (j < total) ? g_S.ref5[m][j] : 128;
       }
     }
   }
-  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) for (int m = 0; m < 5; m++) S->ref5[m][i] = S->ref5b[m][i]; }
-  FCU_FOR_LANES { if (lane < 5) { int sum = 0; for (int i = 0; i < N; i++) sum += S->ref5[lane][2 * N + 1 + i] + S->ref5[lane][2 * N - 1 - i]; S->dc5[lane] = (sum + N) >> (log2 + 1); } }
+  FCU_FOR_LANES { for (int i = lane; i < total; i += 64) if (!avail[i]) for (int m = 0; m < 5; m++) g_S.ref5[m][i] = g_S.ref5b[m][i]; }
+  FCU_FOR_LANES { if (lane < 5) { int sum = 0; for (int i = 0; i < N; i++) sum += g_S.ref5[lane][2 * N + 1 + i] + g_S.ref5[lane][2 * N - 1 - i]; g_S.dc5[lane] = (sum + N) >> (log2 + 1); } }
 }
 
 /* xGetIntraBitsQT(rTu, false, true) for mode slot m from the lane-private coder c (serial, one lane) */
-FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env &E, Cabac *c, const CuObj *cu, int m, int mode, int16_t *absbuf)
+FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env E, int c, const CuObj *cu, int m, int mode, int16_t *absbuf)
 {
   const ChromaModeBuf *B = &E.G->cm[m];
   cab_reset_bits(c);
@@ -1547,7 +1554,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env &E, Cabac *c, const CuO
   for (int pass = 0; pass < 3; pass++) {                      /* 0: subdiv/cbf walk, 1: Cb coefficients, 2: Cr coefficients */
     int sp = 0; tu_root(st[0], cu->depth_cu); ci[0] = -1;
     while (sp >= 0) {
-      const TU &tu = st[sp];
+      const TU tu = st[sp];
       if (ci[sp] < 0) {
         const int subdiv = cu->tr_idx[tu.part] > tu.tr_depth;
         if (pass == 0) {
@@ -1574,14 +1581,14 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env &E, Cabac *c, const CuO
   return cab_bits(c);
 }
 
-FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, n = cu->nparts, cs = (CTU >> d) >> 1;
   int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
   { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
   FCU_FOR_LANES {
-    if (lane < 5) { cab_copy1(&S->lane[lane], slot_ptr(E, d, CI_CURR_BEST)); S->cm_dist[lane] = 0; }
+    if (lane < 5) { cab_copy1(&g_S.cab[CAB_LANE0 + lane], slot_ptr(E, d, CI_CURR_BEST)); g_S.cm_dist[lane] = 0; }
     for (int i = lane; i < 5 * n; i += 64) { const int m = i / n, p = i - m * n; G->cm[m].cbf[0][p] = G->cm[m].cbf[1][p] = 0; G->cm[m].tskip[0][p] = G->cm[m].tskip[1][p] = 0; }
   }
   /* ---- walk the luma TU tree; chroma leaves in z-order ---- */
@@ -1609,7 +1616,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
               for (int i = lane; i < 5 * n2; i += 64) {
                 const int m = i / n2, p = i - m * n2, y = p >> log2, x = p & (N - 1);
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
-                const int pr = pred_pixel(S->ref5[m], log2, mode, 0, S->dc5[m], x, y);
+                const int pr = pred_pixel(g_S.ref5[m], log2, mode, 0, g_S.dc5[m], x, y);
                 G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
               }
             }
@@ -1625,12 +1632,12 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
                 const int m = lane / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
-                S->vc_abs[lane] = rdoq(&S->lane[m], G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
-                S->vc_dist[lane] = 0;
+                g_S.vc_abs[lane] = rdoq((CAB_LANE0 + m), G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
+                g_S.vc_dist[lane] = 0;
               }
               if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
             }
-            FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = S->vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp_c) : 0; } }
+            FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = g_S.vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp_c) : 0; } }
             FCU_FOR_LANES {
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, ts = v % tsv;
@@ -1642,47 +1649,47 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
                 int res = 0;
-                if (S->vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, 0, p);
+                if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, 0, p);
                 const int r = clip8(G->p_pred[m * n2 + p] + res);
                 G->p_rec[i] = (uint8_t)r;
                 const int e = org[y * 32 + x] - r;
-                FCU_ATOMIC_ADD(&S->vc_dist[v], (uint32_t)(e * e));
+                FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
               }
             }
             FCU_FOR_LANES {                                      /* per mode: transform-skip decision (TEncSearch.cpp:1985-2058) */
               if (lane < 5) {
                 const int m = lane; int bestTs = 0;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
-                uint32_t dsel = (uint32_t)(P.chroma_weight * (double)S->vc_dist[m * tsv]);
+                uint32_t dsel = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * tsv]);
                 if (tsv == 2) {
-                  const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)S->vc_dist[m * 2 + 1]);
-                  Cabac *c0 = &S->lane[5 + m], *c1 = &S->lane[10 + m];
-                  cab_copy1(c0, &S->lane[m]); cab_reset_bits(c0);
-                  if (S->vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qcoef + (m * 2) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 0, P, S->lane_abs[lane]);
+                  const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
+                  const int c0 = CAB_LANE0 + 5 + m, c1 = CAB_LANE0 + 10 + m;
+                  cab_copy1(&g_S.cab[c0], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c0);
+                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qcoef + (m * 2) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
                   const double cost0 = rd_cost(P, cab_bits(c0), d0);
                   double cost1 = FCU_MAX_DOUBLE;
-                  if (S->vc_abs[m * 2 + 1] > 0) {
-                    cab_copy1(c1, &S->lane[m]); cab_reset_bits(c1);
-                    code_coeff_nxn(c1, G->p_qcoef + (m * 2 + 1) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 1, P, S->lane_abs[lane]);
+                  if (g_S.vc_abs[m * 2 + 1] > 0) {
+                    cab_copy1(&g_S.cab[c1], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c1);
+                    code_coeff_nxn(c1, G->p_qcoef + (m * 2 + 1) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
                     cost1 = rd_cost(P, cab_bits(c1), d1);
                   }
-                  if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&S->lane[m], c1); } else cab_copy1(&S->lane[m], c0);
+                  if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c1]); } else cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c0]);
                 }
-                S->uni[m] = bestTs;
-                S->cm_dist[m] += dsel;
+                g_S.uni[m] = bestTs;
+                g_S.cm_dist[m] += dsel;
               }
             }
             FCU_FOR_LANES {                                      /* publish the chosen variant into the mode's buffers */
               for (int i = lane; i < 5 * n2; i += 64) {
-                const int m = i / n2, p = i - m * n2, v = m * tsv + S->uni[m], cbf = S->vc_abs[v] > 0;
+                const int m = i / n2, p = i - m * n2, v = m * tsv + g_S.uni[m], cbf = g_S.vc_abs[v] > 0;
                 G->cm[m].coef[comp - 1][tu.off_c + p] = cbf ? G->p_qcoef[v * n2 + p] : (int16_t)0;
                 uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
                 ov[(tu.cy + (p >> log2)) * 32 + tu.cx + (p & (N - 1))] = G->p_rec[v * n2 + p];
               }
               for (int i = lane; i < 5 * nPartsC; i += 64) {
-                const int m = i / nPartsC, p = i - m * nPartsC, v = m * tsv + S->uni[m];
-                G->cm[m].cbf[comp - 1][subPart + p] = (uint8_t)((S->vc_abs[v] > 0 ? 1 : 0) << trDepth);
-                G->cm[m].tskip[comp - 1][subPart + p] = (uint8_t)S->uni[m];
+                const int m = i / nPartsC, p = i - m * nPartsC, v = m * tsv + g_S.uni[m];
+                G->cm[m].cbf[comp - 1][subPart + p] = (uint8_t)((g_S.vc_abs[v] > 0 ? 1 : 0) << trDepth);
+                G->cm[m].tskip[comp - 1][subPart + p] = (uint8_t)g_S.uni[m];
               }
             }
           }
@@ -1710,20 +1717,20 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
           }
         }
       }
-      Cabac *c = &S->lane[5 + m];
-      cab_copy1(c, slot_ptr(E, d, CI_CURR_BEST));
-      S->vc_bits[m] = chroma_tree_bits(E, c, cu, m, modeList[m], S->lane_abs[lane]);
-      S->vc_cost[m] = rd_cost(P, S->vc_bits[m], S->cm_dist[m]);
+      const int c = CAB_LANE0 + 5 + m;
+      cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
+      g_S.vc_bits[m] = chroma_tree_bits(E, c, cu, m, modeList[m], g_S.lane_abs[lane]);
+      g_S.vc_cost[m] = rd_cost(P, g_S.vc_bits[m], g_S.cm_dist[m]);
     }
   }
   FCU_SERIAL {
     double best = FCU_MAX_DOUBLE; int bm = 0;
-    for (int m = 0; m < 5; m++) if (S->vc_cost[m] < best) { best = S->vc_cost[m]; bm = m; }
-    S->c_best_mode = bm;
+    for (int m = 0; m < 5; m++) if (g_S.vc_cost[m] < best) { best = g_S.vc_cost[m]; bm = m; }
+    g_S.c_best_mode = bm;
   }
   {
-    const int bm = S->c_best_mode; const ChromaModeBuf *B = &G->cm[bm];
-    Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+    const int bm = g_S.c_best_mode; const ChromaModeBuf *B = &G->cm[bm];
+    Yuv *recoT = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES {
       for (int i = lane; i < cs * cs; i += 64) {
         cu->coef[1][i] = B->coef[0][i]; cu->coef[2][i] = B->coef[1][i];
@@ -1733,8 +1740,8 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
         cu->cbf[1][i] = B->cbf[0][i]; cu->cbf[2][i] = B->cbf[1][i]; cu->tskip[1][i] = B->tskip[0][i]; cu->tskip[2][i] = B->tskip[1][i];
         cu->intra_dir[1][i] = (uint8_t)modeList[bm];
       }
-      if (lane == 0) cu->dist += S->cm_dist[bm];
-      cab_copy(&S->goon, slot_ptr(E, d, CI_CURR_BEST), lane);
+      if (lane == 0) cu->dist += g_S.cm_dist[bm];
+      cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
     }
   }
 }
@@ -1742,47 +1749,46 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env &E, CuObj *cu)
 /* ======================================================================================== */
 /* CU level: xCheckRDCostIntra / xCheckBestMode / xCompressCU (TEncCu.cpp:460-1616,2064-2255)  */
 /* ======================================================================================== */
-FCU_DEV CuObj *cu_best(const Env &E, int d) { return &E.G->cu[d][E.S->best_idx[d]]; }
-FCU_DEV CuObj *cu_temp(const Env &E, int d) { return &E.G->cu[d][1 - E.S->best_idx[d]]; }
+FCU_DEV CuObj *cu_best(const Env E, int d) { return &E.G->cu[d][g_S.best_idx[d]]; }
+FCU_DEV CuObj *cu_temp(const Env E, int d) { return &E.G->cu[d][1 - g_S.best_idx[d]]; }
 
-FCU_DEV FCU_NOINLINE void check_best_mode(const Env &E, int d)
+FCU_DEV FCU_NOINLINE void check_best_mode(const Env E, int d)
 {
-  Shared *S = E.S;
   const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
   FCU_FOR_LANES {
-    if (change) { cab_copy(slot_ptr(E, d, CI_NEXT_BEST), slot_ptr(E, d, CI_TEMP_BEST), lane); if (lane == 0) { S->best_idx[d] = 1 - S->best_idx[d]; S->reco_best_idx[d] = 1 - S->reco_best_idx[d]; } }
+    if (change) { cab_copy(slot_ptr(E, d, CI_NEXT_BEST), slot_ptr(E, d, CI_TEMP_BEST), lane); if (lane == 0) { g_S.best_idx[d] = 1 - g_S.best_idx[d]; g_S.reco_best_idx[d] = 1 - g_S.reco_best_idx[d]; } }
   }
 }
-FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env &E, int d, int partSize)
+FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env E, int d, int partSize)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   CuObj *cu = cu_temp(E, d);
   const int n = cu->nparts, s = CTU >> d;
   FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTRA; } }
   est_intra_pred_luma(E, cu);
   {
-    const Yuv *recoT = &G->reco[d][1 - S->reco_best_idx[d]];
+    const Yuv *recoT = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES { uint8_t *p = E.C->rec[0] + cu->y * E.C->stride[0] + cu->x; const int rs = E.C->stride[0]; for (int i = lane; i < s * s; i += 64) p[(i / s) * rs + (i % s)] = recoT->y[(i / s) * 64 + (i % s)]; }
   }
   { FCU_TIC(t_); est_intra_pred_chroma(E, cu); FCU_TOC(E, t_, 6); }
   FCU_TIC(t7_);
   FCU_FOR_LANES {
     if (lane == 0) {
-      cab_reset_bits(&S->goon);
-      encode_cu_syntax(E, &S->goon, cu, 0, d);
-      cu->bits = cab_bits(&S->goon); cu->bins = S->goon.bins;
+      cab_reset_bits((CAB_GOON));
+      encode_cu_syntax(E, (CAB_GOON), cu, 0, d);
+      cu->bits = cab_bits((CAB_GOON)); cu->bins = g_S.cab[CAB_GOON].bins;
       cu->cost = rd_cost(P, cu->bits, cu->dist);
     }
   }
-  FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &S->goon, lane);
+  FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane);
   FCU_TOC(E, t7_, 7);
   check_best_mode(E, d);
 }
 
 template <int D>
-FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
+FCU_DEV FCU_NOINLINE void compress_cu(const Env E)
 {
-  Shared *S = E.S; Scratch *G = E.G; const Params &P = E.C->p;
+  Scratch *G = E.G; const Params &P = E.C->p;
   const CuObj *b0 = cu_best(E, D);
   const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
   const int boundary = !((x + s - 1 < P.width) && (y + s - 1 < P.height));
@@ -1802,9 +1808,9 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
     FCU_SERIAL {
       CuObj *best = cu_best(E, D);
       if (best->cost != FCU_MAX_DOUBLE) {                   /* fork: TEncCu.cpp:1224 */
-        cab_reset_bits(&S->goon);
-        code_split_flag(E, &S->goon, best, 0, D);
-        best->bits += cab_bits(&S->goon); best->bins += S->goon.bins;
+        cab_reset_bits((CAB_GOON));
+        code_split_flag(E, (CAB_GOON), best, 0, D);
+        best->bits += cab_bits((CAB_GOON)); best->bins += g_S.cab[CAB_GOON].bins;
         best->cost = rd_cost(P, best->bits, best->dist);
       }
     }
@@ -1821,7 +1827,7 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
         compress_cu<D + 1>(E);
         cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
         {                                                    /* xCopyYuv2Tmp */
-          const Yuv *src = &G->reco[nd][S->reco_best_idx[nd]]; Yuv *dst = &G->reco[D][1 - S->reco_best_idx[D]];
+          const Yuv *src = &G->reco[nd][g_S.reco_best_idx[nd]]; Yuv *dst = &G->reco[D][1 - g_S.reco_best_idx[D]];
           FCU_FOR_LANES {
             for (int k = lane; k < hs * hs; k += 64) dst->y[((i >> 1) * hs + k / hs) * 64 + (i & 1) * hs + k % hs] = src->y[(k / hs) * 64 + k % hs];
             const int h = hs / 2;
@@ -1835,18 +1841,18 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env &E)
     }
     FCU_SERIAL {
       CuObj *t = cu_temp(E, D);
-      if (!boundary) { cab_reset_bits(&S->goon); code_split_flag(E, &S->goon, t, 0, D); t->bits += cab_bits(&S->goon); t->bins += S->goon.bins; }
+      if (!boundary) { cab_reset_bits((CAB_GOON)); code_split_flag(E, (CAB_GOON), t, 0, D); t->bits += cab_bits((CAB_GOON)); t->bins += g_S.cab[CAB_GOON].bins; }
       t->cost = rd_cost(P, t->bits, t->dist);
     }
     FCU_FOR_LANES cab_copy(slot_ptr(E, D, CI_TEMP_BEST), slot_ptr(E, nd, CI_NEXT_BEST), lane);
     check_best_mode(E, D);
   }
   cu_copy_to_pic(E, cu_best(E, D));
-  copy_reco_to_pic(E, &G->reco[D][S->reco_best_idx[D]], x, y, s);
+  copy_reco_to_pic(E, &G->reco[D][g_S.reco_best_idx[D]], x, y, s);
 }
 
 /* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */
-FCU_DEV FCU_NOINLINE void encode_ctu(const Env &E, Cabac *c, const CuObj *ctu, int lastCtuOfSlice)
+FCU_DEV FCU_NOINLINE void encode_ctu(const Env E, int c, const CuObj *ctu, int lastCtuOfSlice)
 {
   const Params &P = E.C->p;
   int stPart[4], stChild[4]; int sp = 0;
@@ -1887,9 +1893,9 @@ FCU_DEV void load_hot_tables()
 }
 
 /* ---- one CTU of one chain: the loop body of TEncSlice::compressSlice, TEncSlice.cpp:1380-1551 */
-FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuRsAddr)
+FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
 {
-  Env E; E.C = C; E.G = G; E.S = S;
+  Env E; E.C = C; E.G = G;
   FCU_TIC(t10_);
   const Params &P = C->p;
   const int sliceLen = P.slice_ctus > 0 ? P.slice_ctus : C->n_ctu;
@@ -1908,8 +1914,8 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
     }
     for (int i = lane; i < 4096; i += 64) out->coeff_y[i] = 0;
     for (int i = lane; i < 1024; i += 64) { out->coeff_cb[i] = 0; out->coeff_cr[i] = 0; }
-    cab_copy(&S->goon, slot_ptr(E, 0, CI_CURR_BEST), lane);
-    if (lane == 0) { for (int d = 0; d < 4; d++) { S->best_idx[d] = 0; S->reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
+    cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
+    if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
   }
   cu_init(E, &G->cu[0][0], 0, x, y, 0);
   cu_init(E, &G->cu[0][1], 0, x, y, 0);
@@ -1926,13 +1932,13 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, Shared *S, int ctuR
       }
       for (int i = lane; i < 4096; i += 64) view->coef[0][i] = (int16_t)out->coeff_y[i];
       for (int i = lane; i < 1024; i += 64) { view->coef[1][i] = (int16_t)out->coeff_cb[i]; view->coef[2][i] = (int16_t)out->coeff_cr[i]; }
-      cab_copy(&S->goon, slot_ptr(E, 0, CI_CURR_BEST), lane);
+      cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
     }
     FCU_TIC(t9_);
     FCU_SERIAL {
-      cab_reset_bits(&S->goon);
-      encode_ctu(E, &S->goon, view, ctuRsAddr == sliceEnd - 1);
-      cab_copy1(&C->state, &S->goon);
+      cab_reset_bits((CAB_GOON));
+      encode_ctu(E, (CAB_GOON), view, ctuRsAddr == sliceEnd - 1);
+      cab_copy1(&C->state, &g_S.cab[CAB_GOON]);
     }
     FCU_TOC(E, t9_, 9);
   }

@@ -20,13 +20,13 @@ using namespace fcu;
 
 /* the chain loop lives in a callable so that the kernel body itself keeps no state across the call
  * (its SGPR spills would otherwise cost two extra VGPRs and the fourth wave per SIMD) */
-__device__ __noinline__ static void run_chain(Chain *C, Scratch *G, Shared *S, int ctus)
+__device__ __noinline__ static void run_chain(Chain *C, Scratch *G, int ctus)
 {
   load_hot_tables();
   for (int k = 0; k < ctus; k++) {
     const int a = C->next_ctu;
     if (a >= C->n_ctu || C->out == nullptr) break;          /* every wave reaches this exit */
-    compress_ctu(C, G, S, a);
+    compress_ctu(C, G, a);
     FCU_SERIAL { C->next_ctu = a + 1; }
   }
 }
@@ -34,8 +34,7 @@ __device__ __noinline__ static void run_chain(Chain *C, Scratch *G, Shared *S, i
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FCU_WAVES_PER_EU, FCU_WAVES_PER_EU)))
 fcu_ctu_engine(Chain *chains, Scratch *scratch, int first, int ctus)
 {
-  __shared__ Shared S;
-  run_chain(&chains[first + blockIdx.x], &scratch[first + blockIdx.x], &S, ctus);
+  run_chain(&chains[first + blockIdx.x], &scratch[first + blockIdx.x], ctus);
 }
 
 /* ---------------------------------------------------------------------------------------- */

@@ -11,7 +11,7 @@
 
 using namespace fcu;
 
-struct EmuChain { Chain c; Scratch *g; Shared *s; };
+struct EmuChain { Chain c; Scratch *g; };
 
 extern "C" {
 void *fcu_emu_create(int width, int height, int qp, int slice_ctus, const uint8_t *oy, const uint8_t *ou, const uint8_t *ov,
@@ -27,11 +27,10 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, const uint8_
   e->c.w_ctu = (width + 63) / 64; e->c.h_ctu = (height + 63) / 64; e->c.n_ctu = e->c.w_ctu * e->c.h_ctu;
   load_hot_tables();
   e->g = (Scratch *)calloc(1, sizeof(Scratch));
-  e->s = (Shared *)calloc(1, sizeof(Shared));
   return e;
 }
-void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); free(e->s); delete e; }
-void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, e->s, a); e->c.next_ctu = a + 1; }
+void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); delete e; }
+void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, a); e->c.next_ctu = a + 1; }
 void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX); *frac = e->c.state.frac; }
 unsigned long long fcu_emu_tu_trials(void *h) { return ((EmuChain *)h)->c.n_tu_trials; }
 int fcu_emu_sizes(int which) { return which == 0 ? (int)sizeof(Scratch) : which == 1 ? (int)sizeof(Shared) : (int)sizeof(Chain); }
