@@ -27,6 +27,7 @@
 
 #ifdef FCU_EMU
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #define FCU_DEV static inline
 #define FCU_NOINLINE
@@ -34,6 +35,7 @@
 #define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
 #define FCU_FLOOR(x) floor(x)
+#define FCU_CHECK(c) do { if (!(c)) { fprintf(stderr, "FCU_CHECK failed: %s (line %d)\n", #c, __LINE__); abort(); } } while (0)
 #else
 #define FCU_DEV __device__ static
 #define FCU_NOINLINE __noinline__
@@ -41,6 +43,7 @@
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define FCU_FLOOR(x) floor(x)
+#define FCU_CHECK(c) do { } while (0)
 #endif
 #define FCU_SERIAL FCU_FOR_LANES if (lane == 0)
 /* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
@@ -74,7 +77,7 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
        CTX_TSKIP = 157, NCTX = 160 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
-enum { MAXVC = 20, POOL = 5120, DIFFN = 512 };
+enum { MAXVC = 20, POOL = 5120, DIFFN = 512 };   /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
 #define FCU_MAX_DOUBLE 1.7e+308
 
 /* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
@@ -114,6 +117,9 @@ struct Yuv { uint8_t y[64 * 64], u[32 * 32], v[32 * 32]; };
 /* state of one chroma-mode trial: the mode's own reconstruction (overlay of PicYuvRec inside the CU), levels, flags */
 struct ChromaModeBuf { uint8_t u[32 * 32], v[32 * 32]; int16_t coef[2][1024]; uint8_t cbf[2][NPART], tskip[2][NPART]; };
 
+/* RDOQ's per-coefficient locals as one record (TComTrQuant.cpp:2082-2095) */
+struct RdoqRec { double cc, cs, c0; int32_t up, dn, sd, du; };   /* pdCostCoeff, pdCostSig, pdCostCoeff0, rateIncUp/Down, sigRateDelta, deltaU */
+
 /* per-chain scratch in HBM (L2 resident working set) */
 struct Scratch {
   CuObj cu[4][2];
@@ -126,8 +132,10 @@ struct Scratch {
   Cabac slots[MAXDEPTH + 2][CI_NUM];               /* the colder snapshots (NEXT/TEMP_BEST, QT_TRAFO_*) live in L2 */
   /* candidate pools: slot v occupies [v*N*N, (v+1)*N*N) */
   uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; int16_t p_qcoef[POOL]; uint8_t p_rec[POOL];
-  /* RDOQ locals (TComTrQuant.cpp:2082-2095) */
-  double r_cc[POOL], r_cs[POOL], r_c0[POOL]; int32_t r_up[POOL], r_dn[POOL], r_sd[POOL], r_du[POOL]; double r_cg[MAXVC * 64];
+  /* scan-order domain of a batch: element (scan position sp, slot v) at [sp * nslots + v] */
+  int32_t p_lscan[POOL]; int16_t p_qscan[POOL];
+  /* RDOQ locals (TComTrQuant.cpp:2082-2095), same interleaving */
+  RdoqRec r_rec[POOL]; double r_cg[MAXVC * 64];
 };
 
 /* per-chain LDS */
@@ -137,16 +145,18 @@ struct Shared {
   Cabac cab[1 + (MAXDEPTH + 1) + MAXVC];
   uint8_t ref[264], reff[264];
   uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
-  int16_t lane_abs[MAXVC][16];                      /* per-lane |level| list of the coefficient group being coded */
+  union {                                           /* never live at the same time */
+    int16_t lane_abs[MAXVC][16];                    /* per-lane |level| list of the coefficient group being coded */
+    int32_t colsum[128];                            /* SATD column sums / availability flags of build_ref */
+  };
   int16_t diff[DIFFN];
-  int32_t colsum[128];
   uint32_t sad[36];
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
   /* PU / TU mailbox written by serial blocks */
   int rd_mode[12]; int n_rd;
   int preds[3]; int n_mpm;
-  int vc_abs[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* MAXVC >= 15: chroma uses [10..14] of vc_dist */
+  int vc_abs[MAXVC], vc_nsig[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
   int pu_best_vc, pu_best_mode; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
   int t_abs; uint32_t t_dist;
@@ -295,22 +305,27 @@ FCU_DEV void code_coef_remain(int c, uint32_t symbol, uint32_t rparam)      /* T
     cab_ep(c, (int)(3 + length + 1 - rparam)); cab_ep(c, (int)length);
   }
 }
-/* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535 */
-FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
+/* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535.
+ * SO = 0: `coef` is the TU in raster order (CU objects).  SO = 1: `coef` holds the levels in scan order
+ * with element stride `st` (the layout RDOQ produces: consecutive scan positions are consecutive
+ * records, the candidates of a batch are interleaved).  numSig < 0: count the non-zero levels here. */
+template <int SO>
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int numSig, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
 {
+#define FCU_CF(sp, blk) (SO ? coef[(sp) * st] : coef[blk])
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
-  int numSig = 0;
-  for (int i = 0; i < n2; i++) numSig += coef[i] != 0;
+  if (numSig < 0) { numSig = 0; for (int i = 0; i < n2; i++) numSig += coef[SO ? i * st : i] != 0; }
   if (numSig == 0) return;                                    /* never called on empty TUs */
   if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
-  int scanPosLast = -1, posLast;
+  int scanPosLast = -1, posLast, lastVal = 0;
   do {
     posLast = scan[++scanPosLast];
-    if (coef[posLast] != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag |= 1ull << (wg * (py >> 2) + (px >> 2)); numSig--; }
+    const int v = FCU_CF(scanPosLast, posLast);
+    if (v != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag |= 1ull << (wg * (py >> 2) + (px >> 2)); numSig--; lastVal = v; }
   } while (numSig > 0);
   {
     int py = posLast >> log2, px = posLast - (py << log2);
@@ -333,16 +348,16 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int log2, i
     int numNonZero = 0; const int subPos = sub << 4;
     goRice = 0;
     int lastNZ = -1, firstNZ = 16, escape = 0;
-    if (scanPosSig == scanPosLast) { absCoeff[0] = (int16_t)iabs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
+    if (scanPosSig == scanPosLast) { absCoeff[0] = (int16_t)iabs(lastVal); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgpos = scanCG[sub], cgy = cgpos / wg, cgx = cgpos - cgy * wg;
     if (sub == lastSet || sub == 0) cgflag |= 1ull << cgpos;
     else cab_bin(c, (int)((cgflag >> cgpos) & 1), baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
     if ((cgflag >> cgpos) & 1) {
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int blk = scan[scanPosSig], sig = coef[blk] != 0;
+        const int blk = scan[scanPosSig], v = FCU_CF(scanPosSig, blk), sig = v != 0;
         if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, baseSig + sig_ctx_inc(pattern, firstSig, blk, log2, ch));
-        if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(coef[blk]); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
+        if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(v); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
     if (numNonZero > 0) {
@@ -372,12 +387,27 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int log2, i
         }
     }
   }
+#undef FCU_CF
 }
 
 /* ======================================================================================== */
 /* RDOQ -- per-lane callable (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:2033-2573)     */
+/* Works in the scan-order domain: the producer (forward transform phase) hands over          */
+/* sign * lLevelDouble per scan position, the levels come back per scan position; element     */
+/* stride `st` interleaves the candidates of a batch so that one lane-private iteration of    */
+/* all lanes touches consecutive bytes.  The seven per-coefficient arrays of the reference     */
+/* (:2082-2095) are one record per scan position.                                              */
 /* ======================================================================================== */
-struct RdoqBuf { double *cc, *cs, *c0; int32_t *up, *dn, *sd, *du; double *cg; };
+struct RdoqBuf { RdoqRec *rec; double *cg; };                    /* both with element stride st */
+
+/* sign(coef) * min(|coef| * quantScale, MAX_INT - (1 << (qbits-1)))   (TComTrQuant.cpp:2117-2128) */
+FCU_DEV int32_t level_double(int32_t coef, int qcoef, int qbits)
+{
+  const long long t = (long long)iabs(coef) * qcoef, lim = 2147483647LL - (1LL << (qbits - 1));
+  const int32_t l = (int32_t)(t < lim ? t : lim);
+  return coef < 0 ? -l : l;
+}
+FCU_DEV int rdoq_qbits(int log2, int qp) { return 14 + qp / 6 + (15 - 8 - log2); }
 
 struct LevelBits { int g10, g11, g20, g21; };              /* greater1 / greater2 flag costs of the current contexts */
 FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
@@ -419,18 +449,19 @@ FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *co
   return bestAbs;
 }
 /* `c` is the coder whose contexts estBit() would snapshot (TEncSbac.cpp:1722-1956); cbfCtx
- * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset). Returns uiAbsSum. */
-FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2, int comp, int scanType, int cbfCtx,
+ * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset).
+ * src[sp*st] = level_double() of the coefficient at scan position sp; dst[sp*st] receives its level.
+ * Returns uiAbsSum and the number of non-zero levels. */
+struct RdoqOut { int abs_sum, num_sig; };
+FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int log2, int comp, int scanType, int cbfCtx,
                  const Params &P, const RdoqBuf &rb)
 {
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
-  const int qp = comp ? P.qp_c : P.qp, per = qp / 6, rem = qp % 6;
-  const int tshift = 15 - 8 - log2, qbits = 14 + per + tshift;
+  const int qp = comp ? P.qp_c : P.qp;
+  const int qbits = rdoq_qbits(log2, qp);
   const double lambda = P.rdoq_lambda[comp];
-  const int qcoef = k_quant_scales[rem];
   const double errScale = P.err_scale[ch][log2 - 2];
-  double *costCoeff = rb.cc, *costSig = rb.cs, *costCoeff0 = rb.c0;
-  int32_t *rateIncUp = rb.up, *rateIncDown = rb.dn, *sigRateDelta = rb.sd, *deltaU = rb.du;
+  RdoqRec *rec = rb.rec;
   /* the reference clears all seven arrays; only entries at scan positions <= the last significant one are
    * ever read back (last-position search, group zero-out, sign hiding), and each of those is written below */
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
@@ -441,31 +472,29 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
   int cgLastScanPos = -1; uint32_t ctxSet = 0; int c1 = 1, c2 = 0;
   double baseCost = 0, blockUncodedCost = 0;
   int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
-  const int cgNum = n2 >> 4; int absSum = 0;
+  const int cgNum = n2 >> 4; int absSum = 0, numSig = 0;
 
   for (int cgScanPos = cgNum - 1; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
     double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
-    costCGSig[cgScanPos] = 0;
+    costCGSig[cgScanPos * st] = 0;
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
-      const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
-      const long long tmpLevel = (long long)iabs(src[blk]) * qcoef;
-      const long long lim = 2147483647LL - (1LL << (qbits - 1));
-      const int32_t levelDouble = (int32_t)(tmpLevel < lim ? tmpLevel : lim);
+      const int scanPos = cgScanPos * 16 + posInCG;
+      const int32_t levelDouble = iabs(src[scanPos * st]);
       uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
       if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
       const double err = (double)levelDouble;
       double c0 = err * err * errScale, cc = 0, cs = 0;
       blockUncodedCost += c0;
-      dst[blk] = (int16_t)maxAbsLevel;
+      uint32_t level = maxAbsLevel;
       if (maxAbsLevel > 0 && lastScanPos < 0) {
         lastScanPos = scanPos;
         ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && (scanPos >> 4) > 0) ? 2 : 0));
         cgLastScanPos = cgScanPos;
       }
       if (lastScanPos >= 0) {
-        uint32_t level;
+        const int blk = scan[scanPos];
         const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1, absCtx = CTX_ABS + (int)ctxSet + c2;
         int sdel = 0, rup, rdn = 0;
         LevelBits lb; lb.g10 = ctx_bits(c, oneCtx, 0); lb.g11 = lb.g20 = lb.g21 = 0;
@@ -484,10 +513,9 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
           rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateNow;
           rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateNow;
         } else rup = lb.g10;
-        costCoeff[scanPos] = cc; costCoeff0[scanPos] = c0; costSig[scanPos] = cs;
-        sigRateDelta[blk] = sdel; rateIncUp[blk] = rup; rateIncDown[blk] = rdn;
-        deltaU[blk] = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
-        dst[blk] = (int16_t)level;
+        RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = rup; r.dn = rdn; r.sd = sdel;
+        r.du = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
+        rec[scanPos * st] = r;
         baseCost += cc;
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
@@ -499,9 +527,10 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
           c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
         }
       } else baseCost += c0;
+      dst[scanPos * st] = (int16_t)level;
       rdSigCost += cs;
       if (posInCG == 0) rdSigCost0 = cs;
-      if (dst[blk]) {
+      if (level) {
         cgflag |= 1ull << cgBlk;
         rdCodedLevelandDist += cc - cs;
         rdUncodedDist += c0;
@@ -513,28 +542,28 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
         if (((cgflag >> cgBlk) & 1) == 0) {
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
           baseCost += lambda * (double)ctx_bits(c, ctxSig, 0) - rdSigCost;
-          costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
+          costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
         } else if (cgScanPos < cgLastScanPos) {
           if (nnzBeforePos0 == 0) { baseCost -= rdSigCost0; rdSigCost -= rdSigCost0; }
           double costZeroCG = baseCost;
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
           baseCost += lambda * (double)ctx_bits(c, ctxSig, 1);
           costZeroCG += lambda * (double)ctx_bits(c, ctxSig, 0);
-          costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 1);
+          costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 1);
           costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
           if (costZeroCG < baseCost) {
             cgflag &= ~(1ull << cgBlk); baseCost = costZeroCG;
-            costCGSig[cgScanPos] = lambda * (double)ctx_bits(c, ctxSig, 0);
+            costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
             for (int posInCG = 15; posInCG >= 0; posInCG--) {
-              const int scanPos = cgScanPos * 16 + posInCG, blk = scan[scanPos];
-              if (dst[blk]) { dst[blk] = 0; costCoeff[scanPos] = costCoeff0[scanPos]; costSig[scanPos] = 0; }
+              const int scanPos = cgScanPos * 16 + posInCG;
+              if (dst[scanPos * st]) { dst[scanPos * st] = 0; rec[scanPos * st].cc = rec[scanPos * st].c0; rec[scanPos * st].cs = 0; }
             }
           }
         }
       } else cgflag |= 1ull << cgBlk;
     }
   }
-  if (lastScanPos < 0) return 0;
+  if (lastScanPos < 0) { RdoqOut z = { 0, 0 }; return z; }
 
   double bestCost; int bestLastIdxP1 = 0;
   bestCost = blockUncodedCost + lambda * (double)ctx_bits(c, cbfCtx, 0);
@@ -545,13 +574,14 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
   int foundLast = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos];
-    baseCost -= costCGSig[cgScanPos];
+    baseCost -= costCGSig[cgScanPos * st];
     if ((cgflag >> cgBlk) & 1) {
       for (int posInCG = 15; posInCG >= 0; posInCG--) {
         const int scanPos = cgScanPos * 16 + posInCG;
         if (scanPos > lastScanPos) continue;
-        const int blk = scan[scanPos];
-        if (dst[blk]) {
+        const int lv = dst[scanPos * st];
+        if (lv) {
+          const int blk = scan[scanPos];
           const int py = blk >> log2, px = blk - (py << log2);
           const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
           const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
@@ -564,59 +594,63 @@ FCU_DEV FCU_NOINLINE int rdoq(int c, const int32_t *src, int16_t *dst, int log2,
           if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
           if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
           const double costLast = lambda * r;
-          const double totalCost = baseCost + costLast - costSig[scanPos];
+          const double totalCost = baseCost + costLast - rec[scanPos * st].cs;
           if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
-          if (dst[blk] > 1) { foundLast = 1; break; }
-          baseCost -= costCoeff[scanPos]; baseCost += costCoeff0[scanPos];
-        } else baseCost -= costSig[scanPos];
+          if (lv > 1) { foundLast = 1; break; }
+          baseCost -= rec[scanPos * st].cc; baseCost += rec[scanPos * st].c0;
+        } else baseCost -= rec[scanPos * st].cs;
       }
       if (foundLast) break;
     }
   }
   for (int sp = 0; sp < bestLastIdxP1; sp++) {
-    const int blk = scan[sp]; const int level = dst[blk];
-    absSum += level;
-    dst[blk] = (int16_t)((src[blk] < 0) ? -level : level);
+    const int level = dst[sp * st];
+    absSum += level; numSig += level != 0;
+    dst[sp * st] = (int16_t)((src[sp * st] < 0) ? -level : level);
   }
-  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[scan[sp]] = 0;
+  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[sp * st] = 0;
 
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
     for (int subSet = (n2 - 1) >> 4; subSet >= 0; subSet--) {
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
-      for (n = 15; n >= 0; --n) if (dst[scan[n + subPos]]) { lastNZ = n; break; }
-      for (n = 0; n < 16; n++) if (dst[scan[n + subPos]]) { firstNZ = n; break; }
-      for (n = firstNZ; n <= lastNZ; n++) sum += dst[scan[n + subPos]];
+      for (n = 15; n >= 0; --n) if (dst[(n + subPos) * st]) { lastNZ = n; break; }
+      for (n = 0; n < 16; n++) if (dst[(n + subPos) * st]) { firstNZ = n; break; }
+      for (n = firstNZ; n <= lastNZ; n++) sum += dst[(n + subPos) * st];
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = dst[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+        const uint32_t signbit = dst[(subPos + firstNZ) * st] > 0 ? 0 : 1;
         if (signbit != (uint32_t)(sum & 1)) {
           long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
           int minPos = -1, finalChange = 0, curChange = 0;
           for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
-            const int blk = scan[n + subPos];
-            if (dst[blk] != 0) {
-              const long long costUp = rdFactor * (-deltaU[blk]) + rateIncUp[blk];
-              long long costDown = rdFactor * (deltaU[blk]) + rateIncDown[blk] - ((iabs(dst[blk]) == 1) ? sigRateDelta[blk] : 0);
-              if (lastCG == 1 && lastNZ == n && iabs(dst[blk]) == 1) costDown -= (4 << 15);
+            const int sp = n + subPos; const int lv = dst[sp * st]; const RdoqRec &q = rec[sp * st];
+            if (lv != 0) {
+              const long long costUp = rdFactor * (-q.du) + q.up;
+              long long costDown = rdFactor * (q.du) + q.dn - ((iabs(lv) == 1) ? q.sd : 0);
+              if (lastCG == 1 && lastNZ == n && iabs(lv) == 1) costDown -= (4 << 15);
               if (costUp < costDown) { curCost = costUp; curChange = 1; }
-              else { curChange = -1; if (n == firstNZ && iabs(dst[blk]) == 1) curCost = 0x7fffffffffffffffLL; else curCost = costDown; }
+              else { curChange = -1; if (n == firstNZ && iabs(lv) == 1) curCost = 0x7fffffffffffffffLL; else curCost = costDown; }
             } else {
-              curCost = rdFactor * (-(long long)(iabs(deltaU[blk]))) + (1 << 15) + rateIncUp[blk] + sigRateDelta[blk];
+              curCost = rdFactor * (-(long long)(iabs(q.du))) + (1 << 15) + q.up + q.sd;
               curChange = 1;
-              if (n < firstNZ) { const uint32_t thissign = src[blk] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
+              if (n < firstNZ) { const uint32_t thissign = src[sp * st] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
             }
-            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = blk; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = sp; }
           }
-          if (dst[minPos] == 32767 || dst[minPos] == -32768) finalChange = -1;
-          if (src[minPos] >= 0) dst[minPos] = (int16_t)(dst[minPos] + finalChange); else dst[minPos] = (int16_t)(dst[minPos] - finalChange);
+          const int old = dst[minPos * st];
+          if (old == 32767 || old == -32768) finalChange = -1;
+          const int nv = src[minPos * st] >= 0 ? old + finalChange : old - finalChange;
+          dst[minPos * st] = (int16_t)nv;
+          numSig += ((int16_t)nv != 0) - (old != 0);
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
-  return absSum;
+  RdoqOut o = { absSum, numSig };
+  return o;
 }
 
 /* ======================================================================================== */
@@ -865,7 +899,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env E, int c, const CuObj *cu, cons
           const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
-          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn<0>(c, buf + (comp ? tu.off_c : tu.off_y), 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -923,7 +957,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(const Env E, int c, const CuObj *cu, 
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
           const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
-          code_coeff_nxn(c, coef, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn<0>(c, coef, 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -1048,18 +1082,21 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
       }
     }
   }
-  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = (int32_t)G->p_resi[i] << (15 - 8 - log2); } }
+  /* forward transform; the coefficients go to RDOQ as sign * lLevelDouble in scan order */
+  const int scanType = coef_scan_idx(mode, log2, comp), qbits = rdoq_qbits(log2, qp), qscale = k_quant_scales[qp % 6];
+  const uint16_t *iscan = k_iscan + k_scan_off[scanType * 4 + log2 - 2];
+  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_lscan[iscan[i]] = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); } }
   else {
     FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1(G->p_resi, log2, useDst, i); }
-    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = fwd2(G->p_tmp, log2, useDst, i); }
+    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_lscan[iscan[i]] = level_double(fwd2(G->p_tmp, log2, useDst, i), qscale, qbits); }
   }
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
     if (lane == 0) {
       FCU_TIC(t8_);
-      RdoqBuf rb = { G->r_cc, G->r_cs, G->r_c0, G->r_up, G->r_dn, G->r_sd, G->r_du, G->r_cg };
+      RdoqBuf rb = { G->r_rec, G->r_cg };
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      g_S.t_abs = rdoq(cab, G->p_tcoef, G->p_qcoef, log2, comp, coef_scan_idx(mode, log2, comp), cbfCtx, P, rb);
+      g_S.t_abs = rdoq(cab, G->p_lscan, G->p_qscan, 1, log2, comp, scanType, cbfCtx, P, rb).abs_sum;
       E.C->n_tu_trials++;
       FCU_TOC(E, t8_, 8);
     }
@@ -1068,7 +1105,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
   FCU_FOR_LANES {                                            /* setCbfPartRange + coefficient store */
     const int np = comp ? tu_nparts_c(tu) : tu.nparts;
     for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
-    for (int i = lane; i < n2; i += 64) { const int q = absSum > 0 ? G->p_qcoef[i] : 0; coef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
+    for (int i = lane; i < n2; i += 64) { const int q = absSum > 0 ? G->p_qscan[iscan[i]] : 0; coef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
   }
   if (absSum > 0) {
     if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
@@ -1334,6 +1371,8 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
   int checkTS = P.transform_skip && log2 == 2;
   if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
   const int nc = g_S.n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
+  FCU_CHECK(nvc <= MAXVC && nvc * n2 <= POOL);
+  const int qbits = rdoq_qbits(log2, P.qp), qscale = k_quant_scales[P.qp % 6];
   const int useDst = log2 == 2;
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   /* reference samples are shared by all candidates: the TU is the whole PU */
@@ -1351,22 +1390,32 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
   FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
-      G->p_tcoef[i] = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
+      const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
+      const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
+      G->p_lscan[iscan[p] * nvc + v] = level_double(t, qscale, qbits);
     }
   }
   FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
     if (lane < nvc) {
       const int mode = g_S.rd_mode[lane / tsv];
-      RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
+      RdoqBuf rb = { G->r_rec + lane, G->r_cg + lane };
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      g_S.vc_abs[lane] = rdoq(CAB_CUR0 + d, G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
+      const RdoqOut o = rdoq(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
+      g_S.vc_abs[lane] = o.abs_sum; g_S.vc_nsig[lane] = o.num_sig;
       g_S.vc_dist[lane] = 0;
     }
     if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
   }
   FCU_TOC(E, t2_, 2);
-  FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = g_S.vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp) : 0; } }
+  FCU_FOR_LANES {                                            /* levels back to raster order + dequantisation */
+    for (int i = lane; i < nvc * n2; i += 64) {
+      const int v = i / n2, p = i - v * n2;
+      const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v / tsv], log2, 0) * 4 + log2 - 2];
+      const int q = g_S.vc_abs[v] > 0 ? G->p_qscan[iscan[p] * nvc + v] : 0;
+      G->p_qcoef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, P.qp);
+    }
+  }
   FCU_FOR_LANES {
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2, ts = v % tsv;
@@ -1387,8 +1436,9 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
   }
   FCU_TIC(t3_);
   FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
-    if (lane < nvc) {
-      const int cnd = lane / tsv, ts = lane % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[lane] > 0;
+    const int vc = lane;
+    if (vc < nvc) {
+      const int cnd = vc / tsv, ts = vc % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[vc] > 0;
       double cost;
       if (ts && !cbf) cost = FCU_MAX_DOUBLE;                 /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
       else {
@@ -1400,11 +1450,11 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
         if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
           cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn(c, G->p_qcoef + lane * n2, log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
-        g_S.vc_bits[lane] = cab_bits(c);
-        cost = rd_cost(P, g_S.vc_bits[lane], g_S.vc_dist[lane]);
+        if (cbf) code_coeff_nxn<1>(c, G->p_qscan + vc, nvc, g_S.vc_nsig[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
+        g_S.vc_bits[vc] = cab_bits(c);
+        cost = rd_cost(P, g_S.vc_bits[vc], g_S.vc_dist[vc]);
       }
-      g_S.vc_cost[lane] = cost;
+      g_S.vc_cost[vc] = cost;
     }
   }
   FCU_TOC(E, t3_, 3);
@@ -1568,7 +1618,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env E, int c, const CuObj *
           if (tu.cw != 0 && ((B->cbf[k][tu.part] >> tu.tr_depth) & 1)) {
             const int log2 = ilog2(tu.cw), pc = tu_part_c(tu);
             const int fmode = mode == DM_CHROMA ? cu->intra_dir[0][pc & ~3] : mode;
-            code_coeff_nxn(c, B->coef[k] + tu.off_c, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
+            code_coeff_nxn<0>(c, B->coef[k] + tu.off_c, 1, -1, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
           }
         }
         if (!subdiv) { sp--; continue; }
@@ -1607,6 +1657,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
             if (checkTS) { int nb = 0; const int maxp = tu.part + (tu.c_code_all ? 1 : 4); for (int p = tu.part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
           }
           const int tsv = checkTS ? 2 : 1, nvc = 5 * tsv;
+          const int qbits = rdoq_qbits(log2, P.qp_c), qscale = k_quant_scales[P.qp_c % 6];
           const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
           for (int comp = 1; comp < 3; comp++) {
             const int px = (cu->x >> 1) + tu.cx, py = (cu->y >> 1) + tu.cy;
@@ -1624,20 +1675,32 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
             FCU_FOR_LANES {
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
-                G->p_tcoef[i] = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + m * n2, log2, 0, p);
+                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
+                const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + m * n2, log2, 0, p);
+                G->p_lscan[iscan[p] * nvc + v] = level_double(t, qscale, qbits);
               }
             }
             FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
               if (lane < nvc) {
                 const int m = lane / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
-                RdoqBuf rb = { G->r_cc + lane * n2, G->r_cs + lane * n2, G->r_c0 + lane * n2, G->r_up + lane * n2, G->r_dn + lane * n2, G->r_sd + lane * n2, G->r_du + lane * n2, G->r_cg + lane * 64 };
-                g_S.vc_abs[lane] = rdoq((CAB_LANE0 + m), G->p_tcoef + lane * n2, G->p_qcoef + lane * n2, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
+                RdoqBuf rb = { G->r_rec + lane, G->r_cg + lane };
+                const RdoqOut o = rdoq(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
+                g_S.vc_abs[lane] = o.abs_sum; g_S.vc_nsig[lane] = o.num_sig;
                 g_S.vc_dist[lane] = 0;
               }
               if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
             }
-            FCU_FOR_LANES { for (int i = lane; i < nvc * n2; i += 64) { const int v = i / n2; G->p_tmp[i] = g_S.vc_abs[v] > 0 ? dequant1(G->p_qcoef[i], log2, P.qp_c) : 0; } }
+            FCU_FOR_LANES {                                      /* levels back to raster order + dequantisation */
+              for (int i = lane; i < nvc * n2; i += 64) {
+                const int v = i / n2, p = i - v * n2, m = v / tsv;
+                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
+                const int q = g_S.vc_abs[v] > 0 ? G->p_qscan[iscan[p] * nvc + v] : 0;
+                G->p_qcoef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, P.qp_c);
+              }
+            }
             FCU_FOR_LANES {
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, ts = v % tsv;
@@ -1665,12 +1728,12 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
                   const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
                   const int c0 = CAB_LANE0 + 5 + m, c1 = CAB_LANE0 + 10 + m;
                   cab_copy1(&g_S.cab[c0], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c0);
-                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qcoef + (m * 2) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
+                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn<1>(c0, G->p_qscan + m * 2, nvc, g_S.vc_nsig[m * 2], log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
                   const double cost0 = rd_cost(P, cab_bits(c0), d0);
                   double cost1 = FCU_MAX_DOUBLE;
                   if (g_S.vc_abs[m * 2 + 1] > 0) {
                     cab_copy1(&g_S.cab[c1], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c1);
-                    code_coeff_nxn(c1, G->p_qcoef + (m * 2 + 1) * n2, log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
+                    code_coeff_nxn<1>(c1, G->p_qscan + m * 2 + 1, nvc, g_S.vc_nsig[m * 2 + 1], log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
                     cost1 = rd_cost(P, cab_bits(c1), d1);
                   }
                   if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c1]); } else cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c0]);
