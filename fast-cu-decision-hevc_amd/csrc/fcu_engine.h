@@ -34,6 +34,9 @@
 #define FCU_TABLE static const
 #define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
+#define FCU_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
+#define FCU_IN_LDS(p) do { } while (0)
+#define FCU_UNI(x) (x)
 #define FCU_FLOOR(x) floor(x)
 #define FCU_CHECK(c) do { if (!(c)) { fprintf(stderr, "FCU_CHECK failed: %s (line %d)\n", #c, __LINE__); abort(); } } while (0)
 #else
@@ -42,6 +45,23 @@
 #define FCU_TABLE __device__ static const
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define FCU_ATOMIC_MAX(p, v) atomicMax((p), (v))
+/* address-space fact for a pointer that crossed a call boundary (lets the compiler emit ds_ instead of flat_ accesses) */
+/* wave-uniform value -> scalar registers.  Everything the orchestration code passes around (chain/scratch/CU
+ * pointers, TU descriptors, depths) is the same in all lanes; saying so keeps it in SGPRs, turns the control
+ * flow into scalar branches and keeps such values out of VGPR spill code around calls. */
+template <class T> __device__ inline T fcu_uni(T v)
+{
+  static_assert(sizeof(T) % 4 == 0, "dword-sized objects only");
+  int w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
+#define FCU_UNI(x) fcu_uni(x)
+#define FCU_GENERIC_(p) ((const __attribute__((address_space(0))) void *)(p))
+#define FCU_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared(FCU_GENERIC_(p)))
 #define FCU_FLOOR(x) floor(x)
 #define FCU_CHECK(c) do { } while (0)
 #endif
@@ -131,7 +151,7 @@ struct Scratch {
   ChromaModeBuf cm[5];
   Cabac slots[MAXDEPTH + 2][CI_NUM];               /* the colder snapshots (NEXT/TEMP_BEST, QT_TRAFO_*) live in L2 */
   /* candidate pools: slot v occupies [v*N*N, (v+1)*N*N) */
-  uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; int16_t p_qcoef[POOL]; uint8_t p_rec[POOL];
+  uint8_t p_pred[POOL]; int16_t p_resi[POOL]; int32_t p_tmp[POOL]; int32_t p_tcoef[POOL]; uint8_t p_rec[POOL];
   /* scan-order domain of a batch: element (scan position sp, slot v) at [sp * nslots + v] */
   int32_t p_lscan[POOL]; int16_t p_qscan[POOL];
   /* RDOQ locals (TComTrQuant.cpp:2082-2095), same interleaving */
@@ -156,10 +176,10 @@ struct Shared {
   /* PU / TU mailbox written by serial blocks */
   int rd_mode[12]; int n_rd;
   int preds[3]; int n_mpm;
-  int vc_abs[MAXVC], vc_nsig[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
-  int pu_best_vc, pu_best_mode; uint32_t pu_best_dist; double pu_best_cost;
+  int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
+  int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
-  int t_abs; uint32_t t_dist;
+  int t_abs, t_lsp, t_last; uint32_t t_dist;
   /* RQT recursion results */
   double q_cost[4]; uint32_t q_dist[4];
   /* chroma search */
@@ -306,27 +326,24 @@ FCU_DEV void code_coef_remain(int c, uint32_t symbol, uint32_t rparam)      /* T
   }
 }
 /* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535.
- * SO = 0: `coef` is the TU in raster order (CU objects).  SO = 1: `coef` holds the levels in scan order
- * with element stride `st` (the layout RDOQ produces: consecutive scan positions are consecutive
- * records, the candidates of a batch are interleaved).  numSig < 0: count the non-zero levels here. */
-template <int SO>
-FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int numSig, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
+ * Inside the engine the levels of a TU are kept in SCAN ORDER (coef[sp * st] = level at scan position sp;
+ * st = 1 in CU objects, st = number of slots in an interleaved candidate batch), so the coder walks memory
+ * linearly.  `last` = scan position of the last non-zero level, or -1: find it here (returns at once on an
+ * all-zero TU).  The significant-group flags the reference gathers in its first loop (:1255-1275) are
+ * derived group by group on the way down (a group's right/below neighbours come earlier in reverse scan). */
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int last, int log2, int comp, int scanType, int tsFlag, const Params &P_, int16_t *absCoeff)
 {
-#define FCU_CF(sp, blk) (SO ? coef[(sp) * st] : coef[blk])
+  const Params &P = *FCU_UNI(&P_);
+  st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp);
+  FCU_IN_LDS(absCoeff);
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
-  if (numSig < 0) { numSig = 0; for (int i = 0; i < n2; i++) numSig += coef[SO ? i * st : i] != 0; }
-  if (numSig == 0) return;                                    /* never called on empty TUs */
+  if (last < 0) { last = n2 - 1; while (last >= 0 && coef[last * st] == 0) last--; if (last < 0) return; }
   if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
-  int scanPosLast = -1, posLast, lastVal = 0;
-  do {
-    posLast = scan[++scanPosLast];
-    const int v = FCU_CF(scanPosLast, posLast);
-    if (v != 0) { int py = posLast >> log2, px = posLast - (py << log2); cgflag |= 1ull << (wg * (py >> 2) + (px >> 2)); numSig--; lastVal = v; }
-  } while (numSig > 0);
+  const int scanPosLast = last, posLast = scan[last], lastVal = coef[last * st];
   {
     int py = posLast >> log2, px = posLast - (py << log2);
     if (scanType == 2) { int t = px; px = py; py = t; }
@@ -351,11 +368,16 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
     if (scanPosSig == scanPosLast) { absCoeff[0] = (int16_t)iabs(lastVal); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgpos = scanCG[sub], cgy = cgpos / wg, cgx = cgpos - cgy * wg;
     if (sub == lastSet || sub == 0) cgflag |= 1ull << cgpos;
-    else cab_bin(c, (int)((cgflag >> cgpos) & 1), baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
+    else {
+      int any = 0;
+      for (int k = 0; k < 16; k++) any |= coef[(subPos + k) * st];
+      if (any) cgflag |= 1ull << cgpos;
+      cab_bin(c, any != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
+    }
     if ((cgflag >> cgpos) & 1) {
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int blk = scan[scanPosSig], v = FCU_CF(scanPosSig, blk), sig = v != 0;
+        const int blk = scan[scanPosSig], v = coef[scanPosSig * st], sig = v != 0;
         if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, baseSig + sig_ctx_inc(pattern, firstSig, blk, log2, ch));
         if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(v); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
@@ -387,7 +409,6 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
         }
     }
   }
-#undef FCU_CF
 }
 
 /* ======================================================================================== */
@@ -398,7 +419,6 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
 /* all lanes touches consecutive bytes.  The seven per-coefficient arrays of the reference     */
 /* (:2082-2095) are one record per scan position.                                              */
 /* ======================================================================================== */
-struct RdoqBuf { RdoqRec *rec; double *cg; };                    /* both with element stride st */
 
 /* sign(coef) * min(|coef| * quantScale, MAX_INT - (1 << (qbits-1)))   (TComTrQuant.cpp:2117-2128) */
 FCU_DEV int32_t level_double(int32_t coef, int qcoef, int qbits)
@@ -408,6 +428,8 @@ FCU_DEV int32_t level_double(int32_t coef, int qcoef, int qbits)
   return coef < 0 ? -l : l;
 }
 FCU_DEV int rdoq_qbits(int log2, int qp) { return 14 + qp / 6 + (15 - 8 - log2); }
+/* uiMaxAbsLevel > 0 for this level_double() value (:2130) */
+FCU_DEV int level_nonzero(int32_t ld, int qbits) { return iabs(ld) >= ((int32_t)1 << (qbits - 1)); }
 
 struct LevelBits { int g10, g11, g20, g21; };              /* greater1 / greater2 flag costs of the current contexts */
 FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx)
@@ -451,30 +473,41 @@ FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *co
 /* `c` is the coder whose contexts estBit() would snapshot (TEncSbac.cpp:1722-1956); cbfCtx
  * is the QT-CBF context of this TU (getCtxQtCbf + getCBFContextOffset).
  * src[sp*st] = level_double() of the coefficient at scan position sp; dst[sp*st] receives its level.
- * Returns uiAbsSum and the number of non-zero levels. */
-struct RdoqOut { int abs_sum, num_sig; };
-FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int log2, int comp, int scanType, int cbfCtx,
-                 const Params &P, const RdoqBuf &rb)
+ * topNZ = highest scan position whose uiMaxAbsLevel is > 0 (found by the producer phase; -1: none).
+ * Levels are written for the scan positions of coefficient groups <= topNZ/16 only; everything above is
+ * zero by construction and the consumers know topNZ.  Returns uiAbsSum and the scan position of the last
+ * non-zero level (-1: none). */
+struct RdoqOut { int abs_sum, last; };
+FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
 {
+  const Params &P = *FCU_UNI(&P_);
+  st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp); cbfCtx = FCU_UNI(cbfCtx);
+  if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? P.qp_c : P.qp;
   const int qbits = rdoq_qbits(log2, qp);
   const double lambda = P.rdoq_lambda[comp];
   const double errScale = P.err_scale[ch][log2 - 2];
-  RdoqRec *rec = rb.rec;
   /* the reference clears all seven arrays; only entries at scan positions <= the last significant one are
    * ever read back (last-position search, group zero-out, sign hiding), and each of those is written below */
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
-  double *costCGSig = rb.cg; uint64_t cgflag = 0;
+  uint64_t cgflag = 0;
   int cgLastScanPos = -1; uint32_t ctxSet = 0; int c1 = 1, c2 = 0;
   double baseCost = 0, blockUncodedCost = 0;
   int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
-  const int cgNum = n2 >> 4; int absSum = 0, numSig = 0;
+  int absSum = 0;
 
-  for (int cgScanPos = cgNum - 1; cgScanPos >= 0; cgScanPos--) {
+  /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order) */
+  const int cgTop = topNZ >> 4;
+  for (int scanPos = n2 - 1; scanPos >= (cgTop + 1) * 16; scanPos--) {
+    const double err = (double)iabs(src[scanPos * st]);
+    blockUncodedCost += err * err * errScale;
+  }
+  baseCost = blockUncodedCost;
+  for (int cgScanPos = cgTop; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
     double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
@@ -563,7 +596,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
       } else cgflag |= 1ull << cgBlk;
     }
   }
-  if (lastScanPos < 0) { RdoqOut z = { 0, 0 }; return z; }
+  if (lastScanPos < 0) { RdoqOut z = { 0, -1 }; return z; }
 
   double bestCost; int bestLastIdxP1 = 0;
   bestCost = blockUncodedCost + lambda * (double)ctx_bits(c, cbfCtx, 0);
@@ -605,7 +638,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   }
   for (int sp = 0; sp < bestLastIdxP1; sp++) {
     const int level = dst[sp * st];
-    absSum += level; numSig += level != 0;
+    absSum += level;
     dst[sp * st] = (int16_t)((src[sp * st] < 0) ? -level : level);
   }
   for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[sp * st] = 0;
@@ -613,7 +646,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
-    for (int subSet = (n2 - 1) >> 4; subSet >= 0; subSet--) {
+    for (int subSet = cgTop; subSet >= 0; subSet--) {            /* groups above hold no level */
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
       for (n = 15; n >= 0; --n) if (dst[(n + subPos) * st]) { lastNZ = n; break; }
       for (n = 0; n < 16; n++) if (dst[(n + subPos) * st]) { firstNZ = n; break; }
@@ -643,13 +676,14 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           if (old == 32767 || old == -32768) finalChange = -1;
           const int nv = src[minPos * st] >= 0 ? old + finalChange : old - finalChange;
           dst[minPos * st] = (int16_t)nv;
-          numSig += ((int16_t)nv != 0) - (old != 0);
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
-  RdoqOut o = { absSum, numSig };
+  int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
+  while (last >= 0 && dst[last * st] == 0) last--;
+  RdoqOut o = { absSum, last };
   return o;
 }
 
@@ -710,8 +744,9 @@ FCU_DEV int unit_available(const Env E, int lx, int ly, int cx, int cy)
 
 /* Reference samples of a block (initAdiPatternChType + fillReferenceSamples + smoothing,
  * TComPattern.cpp:104-521) -> g_S.ref (unfiltered), g_S.reff (filtered, luma only), g_S.dc. */
-FCU_DEV FCU_NOINLINE void build_ref(const Env E, int comp, int px, int py, int log2, int wantFilt)
+FCU_DEV FCU_NOINLINE void build_ref(Env E, int comp, int px, int py, int log2, int wantFilt)
 {
+  E = FCU_UNI(E); comp = FCU_UNI(comp); px = FCU_UNI(px); py = FCU_UNI(py); log2 = FCU_UNI(log2); wantFilt = FCU_UNI(wantFilt);
   const int N = 1 << log2, sh = comp ? 1 : 0, unit = 4 >> sh, total = 4 * N + 1;
   const int lx0 = px << sh, ly0 = py << sh;
   const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
@@ -840,8 +875,9 @@ FCU_DEV void code_luma_dir_bits(int c, int dir, const int *preds)
   cab_bin(c, predIdx != -1, CTX_INTRA_LUMA);
   cab_ep(c, predIdx != -1 ? (predIdx ? 2 : 1) : 5);
 }
-FCU_DEV FCU_NOINLINE void code_intra_dir_luma(const Env E, int c, const CuObj *cu, int part, int multiple)
+FCU_DEV FCU_NOINLINE void code_intra_dir_luma(Env E, int c, const CuObj *cu, int part, int multiple)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); part = FCU_UNI(part); multiple = FCU_UNI(multiple);
   int preds[4][3], predIdx[4];
   const int partNum = multiple ? (cu->part_size[part] == SIZE_NxN ? 4 : 1) : 1;
   const int partOffset = (NPART >> (cu->depth[part] << 1)) >> 2;
@@ -859,8 +895,9 @@ FCU_DEV void code_intra_dir_chroma(int c, int dir)       /* TEncSbac.cpp:698-725
 FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
 
 /* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
-FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env E, int c, const CuObj *cu, const TU root, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(Env E, int c, const CuObj *cu, TU root, int bLuma, int bChroma)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -886,8 +923,9 @@ FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(const Env E, int c, const CuObj *cu,
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env E, int c, const CuObj *cu, const TU root, int comp, int realCoeff)
+FCU_DEV FCU_NOINLINE void enc_coeff_qt(Env E, int c, const CuObj *cu, TU root, int comp, int realCoeff)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -899,7 +937,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(const Env E, int c, const CuObj *cu, cons
           const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
-          code_coeff_nxn<0>(c, buf + (comp ? tu.off_c : tu.off_y), 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -918,8 +956,9 @@ FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, 
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
-FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env E, int c, const CuObj *cu, const TU tu, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(Env E, int c, const CuObj *cu, TU tu, int bLuma, int bChroma)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   cab_reset_bits(c);
   enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
   enc_subdiv_cbf_qt(E, c, cu, tu, bLuma, bChroma);
@@ -928,9 +967,29 @@ FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(const Env E, int c, const CuObj *cu,
   return cab_bits(c);
 }
 
-/* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
-FCU_DEV FCU_NOINLINE void encode_transform(const Env E, int c, const CuObj *cu, int cuPart, const TU root)
+/* xGetIntraBitsQT (luma only) for the un-split TU that tu_trial() has just coded: the same bins as
+ * intra_bits_qt() on a leaf, with the PU's MPM list from the RMD (g_S.preds, same intra_dir_predictor call)
+ * and the levels still in scan order in the trial buffers */
+FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(Env E, int c, const CuObj *cu, TU tu)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const int part = tu.part, partSize = cu->part_size[0], log2 = tu.log2;
+  cab_reset_bits(c);
+  if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
+  if (partSize == SIZE_2Nx2N ? (part == 0) : (tu.tr_depth > 0 && (part % (cu->nparts >> 2)) == 0))
+    code_luma_dir_bits(c, cu->intra_dir[0][part], g_S.preds);
+  if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(cu->depth[part], cu->part_size[part]))
+    cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
+  const int cbf = g_S.t_abs > 0;
+  cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+  if (cbf) code_coeff_nxn(c, E.G->p_qscan, 1, g_S.t_lsp, log2, 0, coef_scan_idx(cu->intra_dir[0][part], log2, 0), cu->tskip[0][part], E.C->p, g_S.lane_abs[0]);
+  return cab_bits(c);
+}
+
+/* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
+FCU_DEV FCU_NOINLINE void encode_transform(Env E, int c, const CuObj *cu, int cuPart, TU root)
+{
+  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); root = FCU_UNI(root);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -957,7 +1016,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(const Env E, int c, const CuObj *cu, 
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
           const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
-          code_coeff_nxn<0>(c, coef, 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn(c, coef, 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -979,8 +1038,9 @@ FCU_DEV void encode_cu_syntax(const Env E, int c, const CuObj *cu, int cuPart, i
 /* ======================================================================================== */
 /* CU object helpers (cooperative)                                                           */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void cu_init(const Env E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
+FCU_DEV FCU_NOINLINE void cu_init(Env E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); depth = FCU_UNI(depth); x = FCU_UNI(x); y = FCU_UNI(y); zidx = FCU_UNI(zidx);
   const int n = NPART >> (2 * depth), s = CTU >> depth;
   FCU_FOR_LANES {
     if (lane == 0) { cu->cost = FCU_MAX_DOUBLE; cu->dist = 0; cu->bits = 0; cu->bins = 0; cu->depth_cu = depth; cu->x = x; cu->y = y; cu->zidx = zidx; cu->nparts = n; }
@@ -994,8 +1054,9 @@ FCU_DEV FCU_NOINLINE void cu_init(const Env E, CuObj *cu, int depth, int x, int 
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
+FCU_DEV FCU_NOINLINE void cu_copy_part_from(Env E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
 {
+  E = FCU_UNI(E); dst = FCU_UNI(dst); src = FCU_UNI(src); partUnitIdx = FCU_UNI(partUnitIdx);
   const int n = src->nparts, off = partUnitIdx * n;
   FCU_FOR_LANES {
     if (lane == 0) { dst->dist += src->dist; dst->bits += src->bits; dst->bins += src->bins; }
@@ -1010,8 +1071,9 @@ FCU_DEV FCU_NOINLINE void cu_copy_part_from(const Env E, CuObj *dst, const CuObj
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env E, const CuObj *cu)                             /* copyToPic */
+FCU_DEV FCU_NOINLINE void cu_copy_to_pic(Env E, const CuObj *cu)                             /* copyToPic */
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu);
   fcu_ctu_out *p = &E.C->out[E.cur_ctu];
   const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
   FCU_FOR_LANES {
@@ -1023,12 +1085,35 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const Env E, const CuObj *cu)          
       for (int c = 0; c < 3; c++) { p->tskip[c][off + i] = cu->tskip[c][i]; p->cbf[c][off + i] = cu->cbf[c][i]; }
       p->intra_dir[0][off + i] = cu->intra_dir[0][i]; p->intra_dir[1][off + i] = cu->intra_dir[1][i];
     }
-    for (int i = lane; i < n * 16; i += 64) p->coeff_y[off * 16 + i] = cu->coef[0][i];
-    for (int i = lane; i < n * 4; i += 64) { p->coeff_cb[off * 4 + i] = cu->coef[1][i]; p->coeff_cr[off * 4 + i] = cu->coef[2][i]; }
+    /* m_pcTrCoeff is raster order inside each TU; the engine keeps scan order, converted here.  Only the
+     * depth-0 call matters for the coefficients (it rewrites the whole CTU and nothing reads them before). */
+    if (cu->depth_cu == 0) {
+      for (int i = lane; i < 4096; i += 64) {
+        const int part = i >> 4; int v = 0;
+        if (cu->pred_mode[part] == MODE_INTRA) {
+          const int log2 = 6 - cu->depth[part] - cu->tr_idx[part], np = 1 << (2 * (log2 - 2)), tp = part & ~(np - 1);
+          const int st = coef_scan_idx(cu->intra_dir[0][tp], log2, 0);
+          v = cu->coef[0][tp * 16 + k_iscan[k_scan_off[st * 4 + log2 - 2] + (i - tp * 16)]];
+        }
+        p->coeff_y[i] = v;
+      }
+      for (int i = lane; i < 1024; i += 64) {
+        const int part = i >> 2; int vb = 0, vr = 0;
+        if (cu->pred_mode[part] == MODE_INTRA) {
+          const int ll = 6 - cu->depth[part] - cu->tr_idx[part];            /* luma TU; chroma is half of it, 4x4 covers four luma 4x4 */
+          const int log2 = ll > 2 ? ll - 1 : 2, np = ll > 2 ? 1 << (2 * (ll - 2)) : 4, tp = part & ~(np - 1);
+          const int mode = chroma_final_mode(cu, tp), o = k_scan_off[coef_scan_idx(mode, log2, 1) * 4 + log2 - 2];
+          const int sp = k_iscan[o + (i - tp * 4)];
+          vb = cu->coef[1][tp * 4 + sp]; vr = cu->coef[2][tp * 4 + sp];
+        }
+        p->coeff_cb[i] = vb; p->coeff_cr[i] = vr;
+      }
+    }
   }
 }
-FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env E, const Yuv *r, int x, int y, int s)
+FCU_DEV FCU_NOINLINE void copy_reco_to_pic(Env E, const Yuv *r, int x, int y, int s)
 {
+  E = FCU_UNI(E); r = FCU_UNI(r); x = FCU_UNI(x); y = FCU_UNI(y); s = FCU_UNI(s);
   FCU_FOR_LANES {
     for (int c = 0; c < 3; c++) {
       const int sh = c ? 1 : 0, bs = c ? 32 : 64, w = E.C->p.width >> sh, h = E.C->p.height >> sh;
@@ -1043,10 +1128,12 @@ FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Env E, const Yuv *r, int x, int
 /* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
 /* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp, int cab, int save1load2)
+FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, int save1load2)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp); cab = FCU_UNI(cab); save1load2 = FCU_UNI(save1load2);
   Scratch *G = E.G; const Params &P = E.C->p;
-  if (comp && tu.cw == 0) { FCU_SERIAL { g_S.t_dist = 0; g_S.t_abs = 0; } return; }
+  if (comp && tu.cw == 0) { FCU_SERIAL { g_S.t_dist = 0; g_S.t_abs = 0; g_S.t_lsp = -1; } return; }
+  FCU_TIC(t11_);
   const int d = cu->depth_cu, N = comp ? tu.cw : (1 << tu.log2), log2 = ilog2(N), n2 = N * N;
   const int bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y, bs = comp ? 32 : 64, sh = comp ? 1 : 0;
   const int part = tu.part, layer = LOG2_MAXTU - tu.log2;
@@ -1066,6 +1153,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
     build_ref(E, comp, px, py, log2, filt);
     FCU_FOR_LANES {
       const uint8_t *r = filt ? g_S.reff : g_S.ref; const int dc = g_S.dc;
+      if (lane == 0) g_S.t_last = -1;
       for (int i = lane; i < n2; i += 64) {
         const int y = i >> log2, x = i & (N - 1);
         const int v = pred_pixel(r, log2, mode, comp == 0, dc, x, y);
@@ -1076,6 +1164,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
     }
   } else {
     FCU_FOR_LANES {
+      if (lane == 0) g_S.t_last = -1;
       for (int i = lane; i < n2; i += 64) {
         const int y = i >> log2, x = i & (N - 1); const int v = G->shared_pred[comp][i];
         pred[y * bs + x] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * bs + x] - v);
@@ -1085,18 +1174,19 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
   /* forward transform; the coefficients go to RDOQ as sign * lLevelDouble in scan order */
   const int scanType = coef_scan_idx(mode, log2, comp), qbits = rdoq_qbits(log2, qp), qscale = k_quant_scales[qp % 6];
   const uint16_t *iscan = k_iscan + k_scan_off[scanType * 4 + log2 - 2];
-  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_lscan[iscan[i]] = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); } }
+  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } } }
   else {
     FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1(G->p_resi, log2, useDst, i); }
-    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_lscan[iscan[i]] = level_double(fwd2(G->p_tmp, log2, useDst, i), qscale, qbits); }
+    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2(G->p_tmp, log2, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }
   }
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
     if (lane == 0) {
       FCU_TIC(t8_);
-      RdoqBuf rb = { G->r_rec, G->r_cg };
+      RdoqRec *rrec = G->r_rec; double *rcg = G->r_cg;
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      g_S.t_abs = rdoq(cab, G->p_lscan, G->p_qscan, 1, log2, comp, scanType, cbfCtx, P, rb).abs_sum;
+      const RdoqOut o = rdoq(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
+      g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
       E.C->n_tu_trials++;
       FCU_TOC(E, t8_, 8);
     }
@@ -1105,7 +1195,8 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
   FCU_FOR_LANES {                                            /* setCbfPartRange + coefficient store */
     const int np = comp ? tu_nparts_c(tu) : tu.nparts;
     for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
-    for (int i = lane; i < n2; i += 64) { const int q = absSum > 0 ? G->p_qscan[iscan[i]] : 0; coef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
+    const int cgEnd = ((g_S.t_last >> 4) + 1) << 4;                /* RDOQ wrote the levels of scan positions < cgEnd */
+    for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int q = (absSum > 0 && sp < cgEnd) ? G->p_qscan[sp] : 0; coef[sp] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
   }
   if (absSum > 0) {
     if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
@@ -1128,11 +1219,13 @@ FCU_DEV FCU_NOINLINE void tu_trial(const Env E, CuObj *cu, const TU tu, int comp
     FCU_ATOMIC_ADD(&g_S.sad[35], sse);
   }
   FCU_SERIAL { const uint32_t sse = g_S.sad[35]; g_S.t_dist = comp ? (uint32_t)(P.chroma_weight * (double)sse) : sse; }
+  FCU_TOC(E, t11_, 11);
 }
 
 /* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
-FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env E, const TU tu, int comp)
+FCU_DEV FCU_NOINLINE void store_intra_result_qt(Env E, TU tu, int comp)
 {
+  E = FCU_UNI(E); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1140,8 +1233,9 @@ FCU_DEV FCU_NOINLINE void store_intra_result_qt(const Env E, const TU tu, int co
   const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
   FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
 }
-FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env E, const CuObj *cu, const TU tu, int comp)
+FCU_DEV FCU_NOINLINE void load_intra_result_qt(Env E, const CuObj *cu, TU tu, int comp)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, sh = comp ? 1 : 0, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1156,8 +1250,9 @@ FCU_DEV FCU_NOINLINE void load_intra_result_qt(const Env E, const CuObj *cu, con
 /* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to g_S.q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int checkFirst, int reuseVc = -1)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst, int reuseVc = -1)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); checkFirst = FCU_UNI(checkFirst); reuseVc = FCU_UNI(reuseVc);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
   const int partSize = cu->part_size[part];
@@ -1178,7 +1273,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int
         double tmpCost;
         if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
         else {
-          FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(E, CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
           tmpCost = rd_cost(P, g_S.vc_bits[0], tmpDist);
         }
         if (tmpCost < singleCost) {
@@ -1202,7 +1297,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int
         const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = g_S.vc_abs[bv] > 0;
         FCU_FOR_LANES {
           for (int i = lane; i < n2; i += 64) {
-            G->qt_coef[0][layer][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
+            G->qt_coef[0][layer][tu.off_y + i] = (cbf && (i >> 4) <= (g_S.vc_last[bv] >> 4)) ? G->p_qscan[i * g_S.pu_nvc + bv] : (int16_t)0;
             G->qt_rec[layer].y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
           }
           for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
@@ -1213,7 +1308,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int
         tu_trial(E, cu, tu, 0, (CAB_GOON), 0);
         singleDist = g_S.t_dist;
         if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
-        FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(E, CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
         singleCost = rd_cost(P, g_S.vc_bits[0], singleDist);
       }
     }
@@ -1234,7 +1329,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
         cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
-      FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); }
+      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); } FCU_TOC(E, t12_, 12); }
       const double splitCost = rd_cost(P, g_S.vc_bits[0], splitDist);
       if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; } return; }
       FCU_FOR_LANES {
@@ -1251,8 +1346,9 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(const Env E, CuObj *cu, const TU tu, int
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
-FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env E, CuObj *cu, const TU root, Yuv *reco)
+FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(Env E, CuObj *cu, TU root, Yuv *reco)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); root = FCU_UNI(root); reco = FCU_UNI(reco);
   Scratch *G = E.G;
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -1281,8 +1377,9 @@ FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(const Env E, CuObj *cu, const
 /* RMD: 35 predictions + Hadamard SATD staged through LDS (TEncSearch.cpp:2300-2361,          */
 /* TComRdCost.cpp:1343-1604) and the sorted candidate list (xUpdateCandList :5345-5370)       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void rmd(const Env E, CuObj *cu, const TU tu)
+FCU_DEV FCU_NOINLINE void rmd(Env E, CuObj *cu, TU tu)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
   build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
@@ -1363,8 +1460,9 @@ FCU_DEV FCU_NOINLINE void rmd(const Env E, CuObj *cu, const TU tu)
 /* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
 /* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU tu)
+FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
   const int partSize = cu->part_size[part];
@@ -1386,23 +1484,25 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
       G->p_pred[i] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * 64 + x] - v);
     }
   }
-  FCU_FOR_LANES { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1(G->p_resi + cnd * n2, log2, useDst, i - cnd * n2); } }
+  FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1(G->p_resi + cnd * n2, log2, useDst, i - cnd * n2); } }
   FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
       const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
       const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
-      G->p_lscan[iscan[p] * nvc + v] = level_double(t, qscale, qbits);
+      const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
+      G->p_lscan[sp * nvc + v] = ld;
+      if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
     }
   }
   FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
     if (lane < nvc) {
       const int mode = g_S.rd_mode[lane / tsv];
-      RdoqBuf rb = { G->r_rec + lane, G->r_cg + lane };
+      RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      const RdoqOut o = rdoq(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rb);
-      g_S.vc_abs[lane] = o.abs_sum; g_S.vc_nsig[lane] = o.num_sig;
+      const RdoqOut o = rdoq(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
+      g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
       g_S.vc_dist[lane] = 0;
     }
     if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
@@ -1412,8 +1512,9 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2;
       const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v / tsv], log2, 0) * 4 + log2 - 2];
-      const int q = g_S.vc_abs[v] > 0 ? G->p_qscan[iscan[p] * nvc + v] : 0;
-      G->p_qcoef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, P.qp);
+      const int sp = iscan[p];
+      const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
+      G->p_tmp[i] = dequant1(q, log2, P.qp);
     }
   }
   FCU_FOR_LANES {
@@ -1450,7 +1551,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
         if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
           cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn<1>(c, G->p_qscan + vc, nvc, g_S.vc_nsig[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
+        if (cbf) code_coeff_nxn(c, G->p_qscan + vc, nvc, g_S.vc_lsp[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
         g_S.vc_bits[vc] = cab_bits(c);
         cost = rd_cost(P, g_S.vc_bits[vc], g_S.vc_dist[vc]);
       }
@@ -1465,14 +1566,14 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
       if (tsv == 2 && g_S.vc_cost[v + 1] < c) { v = v + 1; c = g_S.vc_cost[v]; }
       if (c < best) { best = c; bv = v; }
     }
-    g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
+    g_S.pu_nvc = nvc; g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
   }
   {                                                          /* xSetIntraResultLumaQT + decision snapshot */
     const int bv = g_S.pu_best_vc, ts = bv % tsv, cbf = g_S.vc_abs[bv] > 0;
     Yuv *reco = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES {
       for (int i = lane; i < n2; i += 64) {
-        cu->coef[0][tu.off_y + i] = cbf ? G->p_qcoef[bv * n2 + i] : (int16_t)0;
+        cu->coef[0][tu.off_y + i] = (cbf && (i >> 4) <= (g_S.vc_last[bv] >> 4)) ? G->p_qscan[i * nvc + bv] : (int16_t)0;
         reco->y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
       }
       for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = (uint8_t)tu.tr_depth; G->tmp_cbf[i] = (uint8_t)(cbf << tu.tr_depth); G->tmp_tskip[i] = (uint8_t)ts; }
@@ -1483,8 +1584,9 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(const Env E, CuObj *cu, const TU
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void est_intra_pred_luma(const Env E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_luma(Env E, CuObj *cu)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu);
   Scratch *G = E.G;
   const int d = cu->depth_cu, partSize = cu->part_size[0];
   const int initTrDepth = partSize == SIZE_2Nx2N ? 0 : 1, numPU = 1 << (2 * initTrDepth), qNumParts = cu->nparts >> 2;
@@ -1595,8 +1697,10 @@ FCU_DEV void chroma_leaf_refs5(const Env E, const CuObj *cu, int comp, int px, i
 }
 
 /* xGetIntraBitsQT(rTu, false, true) for mode slot m from the lane-private coder c (serial, one lane) */
-FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env E, int c, const CuObj *cu, int m, int mode, int16_t *absbuf)
+FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(Env E, int c, const CuObj *cu, int m, int mode, int16_t *absbuf)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu);
+  FCU_IN_LDS(absbuf);
   const ChromaModeBuf *B = &E.G->cm[m];
   cab_reset_bits(c);
   code_intra_dir_chroma(c, mode);
@@ -1618,7 +1722,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env E, int c, const CuObj *
           if (tu.cw != 0 && ((B->cbf[k][tu.part] >> tu.tr_depth) & 1)) {
             const int log2 = ilog2(tu.cw), pc = tu_part_c(tu);
             const int fmode = mode == DM_CHROMA ? cu->intra_dir[0][pc & ~3] : mode;
-            code_coeff_nxn<0>(c, B->coef[k] + tu.off_c, 1, -1, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
+            code_coeff_nxn(c, B->coef[k] + tu.off_c, 1, -1, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
           }
         }
         if (!subdiv) { sp--; continue; }
@@ -1631,8 +1735,9 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(const Env E, int c, const CuObj *
   return cab_bits(c);
 }
 
-FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
 {
+  E = FCU_UNI(E); cu = FCU_UNI(cu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, n = cu->nparts, cs = (CTU >> d) >> 1;
   int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
@@ -1671,34 +1776,39 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
                 G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
               }
             }
-            FCU_FOR_LANES { for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1(G->p_resi + m * n2, log2, 0, i - m * n2); } }
+            FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1(G->p_resi + m * n2, log2, 0, i - m * n2); } }
             FCU_FOR_LANES {
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
                 const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + m * n2, log2, 0, p);
-                G->p_lscan[iscan[p] * nvc + v] = level_double(t, qscale, qbits);
+                const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
+                G->p_lscan[sp * nvc + v] = ld;
+                if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
               }
             }
+            FCU_TIC(t13_);
             FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
               if (lane < nvc) {
                 const int m = lane / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
-                RdoqBuf rb = { G->r_rec + lane, G->r_cg + lane };
-                const RdoqOut o = rdoq(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rb);
-                g_S.vc_abs[lane] = o.abs_sum; g_S.vc_nsig[lane] = o.num_sig;
+                RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
+                const RdoqOut o = rdoq(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
+                g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
                 g_S.vc_dist[lane] = 0;
               }
               if (lane == 0) E.C->n_tu_trials += (unsigned long long)nvc;
             }
+            FCU_TOC(E, t13_, 13);
             FCU_FOR_LANES {                                      /* levels back to raster order + dequantisation */
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
-                const int q = g_S.vc_abs[v] > 0 ? G->p_qscan[iscan[p] * nvc + v] : 0;
-                G->p_qcoef[i] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, P.qp_c);
+                const int sp = iscan[p];
+                const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
+                G->p_tmp[i] = dequant1(q, log2, P.qp_c);
               }
             }
             FCU_FOR_LANES {
@@ -1728,12 +1838,12 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
                   const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
                   const int c0 = CAB_LANE0 + 5 + m, c1 = CAB_LANE0 + 10 + m;
                   cab_copy1(&g_S.cab[c0], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c0);
-                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn<1>(c0, G->p_qscan + m * 2, nvc, g_S.vc_nsig[m * 2], log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
+                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qscan + m * 2, nvc, g_S.vc_lsp[m * 2], log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
                   const double cost0 = rd_cost(P, cab_bits(c0), d0);
                   double cost1 = FCU_MAX_DOUBLE;
                   if (g_S.vc_abs[m * 2 + 1] > 0) {
                     cab_copy1(&g_S.cab[c1], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c1);
-                    code_coeff_nxn<1>(c1, G->p_qscan + m * 2 + 1, nvc, g_S.vc_nsig[m * 2 + 1], log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
+                    code_coeff_nxn(c1, G->p_qscan + m * 2 + 1, nvc, g_S.vc_lsp[m * 2 + 1], log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
                     cost1 = rd_cost(P, cab_bits(c1), d1);
                   }
                   if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c1]); } else cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c0]);
@@ -1745,7 +1855,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
             FCU_FOR_LANES {                                      /* publish the chosen variant into the mode's buffers */
               for (int i = lane; i < 5 * n2; i += 64) {
                 const int m = i / n2, p = i - m * n2, v = m * tsv + g_S.uni[m], cbf = g_S.vc_abs[v] > 0;
-                G->cm[m].coef[comp - 1][tu.off_c + p] = cbf ? G->p_qcoef[v * n2 + p] : (int16_t)0;
+                G->cm[m].coef[comp - 1][tu.off_c + p] = (cbf && (p >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[p * nvc + v] : (int16_t)0;
                 uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
                 ov[(tu.cy + (p >> log2)) * 32 + tu.cx + (p & (N - 1))] = G->p_rec[v * n2 + p];
               }
@@ -1765,6 +1875,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
     { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
   }
   /* ---- per mode: CBF propagation up the tree, bits, cost ---- */
+  FCU_TIC(t14_);
   FCU_FOR_LANES {
     if (lane < 5) {
       const int m = lane; ChromaModeBuf *B = &G->cm[m];
@@ -1786,6 +1897,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
       g_S.vc_cost[m] = rd_cost(P, g_S.vc_bits[m], g_S.cm_dist[m]);
     }
   }
+  FCU_TOC(E, t14_, 14);
   FCU_SERIAL {
     double best = FCU_MAX_DOUBLE; int bm = 0;
     for (int m = 0; m < 5; m++) if (g_S.vc_cost[m] < best) { best = g_S.vc_cost[m]; bm = m; }
@@ -1815,15 +1927,17 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(const Env E, CuObj *cu)
 FCU_DEV CuObj *cu_best(const Env E, int d) { return &E.G->cu[d][g_S.best_idx[d]]; }
 FCU_DEV CuObj *cu_temp(const Env E, int d) { return &E.G->cu[d][1 - g_S.best_idx[d]]; }
 
-FCU_DEV FCU_NOINLINE void check_best_mode(const Env E, int d)
+FCU_DEV FCU_NOINLINE void check_best_mode(Env E, int d)
 {
+  E = FCU_UNI(E); d = FCU_UNI(d);
   const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
   FCU_FOR_LANES {
     if (change) { cab_copy(slot_ptr(E, d, CI_NEXT_BEST), slot_ptr(E, d, CI_TEMP_BEST), lane); if (lane == 0) { g_S.best_idx[d] = 1 - g_S.best_idx[d]; g_S.reco_best_idx[d] = 1 - g_S.reco_best_idx[d]; } }
   }
 }
-FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env E, int d, int partSize)
+FCU_DEV FCU_NOINLINE void check_rd_cost_intra(Env E, int d, int partSize)
 {
+  E = FCU_UNI(E); d = FCU_UNI(d); partSize = FCU_UNI(partSize);
   Scratch *G = E.G; const Params &P = E.C->p;
   CuObj *cu = cu_temp(E, d);
   const int n = cu->nparts, s = CTU >> d;
@@ -1849,8 +1963,9 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(const Env E, int d, int partSize)
 }
 
 template <int D>
-FCU_DEV FCU_NOINLINE void compress_cu(const Env E)
+FCU_DEV FCU_NOINLINE void compress_cu(Env E)
 {
+  E = FCU_UNI(E);
   Scratch *G = E.G; const Params &P = E.C->p;
   const CuObj *b0 = cu_best(E, D);
   const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
@@ -1915,8 +2030,9 @@ FCU_DEV FCU_NOINLINE void compress_cu(const Env E)
 }
 
 /* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */
-FCU_DEV FCU_NOINLINE void encode_ctu(const Env E, int c, const CuObj *ctu, int lastCtuOfSlice)
+FCU_DEV FCU_NOINLINE void encode_ctu(Env E, int c, const CuObj *ctu, int lastCtuOfSlice)
 {
+  E = FCU_UNI(E); c = FCU_UNI(c); ctu = FCU_UNI(ctu); lastCtuOfSlice = FCU_UNI(lastCtuOfSlice);
   const Params &P = E.C->p;
   int stPart[4], stChild[4]; int sp = 0;
   stPart[0] = 0; stChild[0] = -1;
@@ -1958,6 +2074,7 @@ FCU_DEV void load_hot_tables()
 /* ---- one CTU of one chain: the loop body of TEncSlice::compressSlice, TEncSlice.cpp:1380-1551 */
 FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
 {
+  C = FCU_UNI(C); G = FCU_UNI(G); ctuRsAddr = FCU_UNI(ctuRsAddr);
   Env E; E.C = C; E.G = G;
   FCU_TIC(t10_);
   const Params &P = C->p;
@@ -1985,16 +2102,8 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
   compress_cu<0>(E);
   /* encodeCtu on [0][CI_CURR_BEST] (TEncSlice.cpp:1474-1487): replay the winner to advance the contexts */
   {
-    CuObj *view = cu_temp(E, 0);
+    const CuObj *view = cu_best(E, 0);                     /* what copyToPic has just published (whole CTU) */
     FCU_FOR_LANES {
-      if (lane == 0) { view->depth_cu = 0; view->x = x; view->y = y; view->zidx = 0; view->nparts = NPART; }
-      for (int i = lane; i < NPART; i += 64) {
-        view->depth[i] = out->depth[i]; view->part_size[i] = out->part_size[i]; view->pred_mode[i] = out->pred_mode[i]; view->tr_idx[i] = out->tr_idx[i];
-        for (int c = 0; c < 3; c++) { view->tskip[c][i] = out->tskip[c][i]; view->cbf[c][i] = out->cbf[c][i]; }
-        view->intra_dir[0][i] = out->intra_dir[0][i]; view->intra_dir[1][i] = out->intra_dir[1][i];
-      }
-      for (int i = lane; i < 4096; i += 64) view->coef[0][i] = (int16_t)out->coeff_y[i];
-      for (int i = lane; i < 1024; i += 64) { view->coef[1][i] = (int16_t)out->coeff_cb[i]; view->coef[2][i] = (int16_t)out->coeff_cr[i]; }
       cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
     }
     FCU_TIC(t9_);

@@ -24,7 +24,7 @@ t=time.time()
 for _ in range(reps): eng.compress_chains(0,frames*4,nct//reps)
 eng.sync(); dt=time.time()-t
 print('chains',frames*4,'ctus',nct,'time',dt,'CTU/s',frames*4*nct/dt)
-names=['rmd','pass1_total','pass1_rdoq','pass1_bits','pass2_rqt','chroma_batched','chroma_total','cu_syntax','seq_rdoq','replay','ctu_total']
+names=['rmd','pass1_total','pass1_rdoq','pass1_bits','pass2_rqt','chroma_batched','chroma_total','cu_syntax','seq_rdoq','replay','ctu_total','tu_trial_total','rqt_bits_walk','chroma_rdoq','chroma_tree_bits']
 import numpy as np
 acc=np.zeros(17)
 for c in range(0,frames*4,max(1,frames*4//64)):
