@@ -79,7 +79,8 @@ template <class T> __device__ inline T fcu_uni(T v)
 
 /* hot tables mirrored in LDS (the per-bin cost/transition table is read once per context-coded bin and several
  * times per RDOQ coefficient; on-chip reads keep the vector-memory pipeline for the scratch traffic) */
-struct HotTables { uint32_t bin[256]; uint16_t scan[3][16 + 64]; uint8_t scan_cg8[3][4]; uint8_t ctx_ind_map4x4[16]; uint8_t group_idx[32]; };
+struct HotTables { uint32_t bin[256]; uint16_t scan[3][16 + 64]; uint8_t scan_cg8[3][4]; uint8_t ctx_ind_map4x4[16]; uint8_t group_idx[32];
+                   uint64_t scan4_nib[3], map4_nib; uint32_t cnt_bits[4]; };   /* 4x4 scans / 4x4 sig-ctx map as nibbles, sig-ctx counts per pattern as 2-bit fields */
 #ifdef FCU_EMU
 static HotTables g_hot;
 #else
@@ -331,8 +332,11 @@ FCU_DEV void code_coef_remain(int c, uint32_t symbol, uint32_t rparam)      /* T
  * linearly.  `last` = scan position of the last non-zero level, or -1: find it here (returns at once on an
  * all-zero TU).  The significant-group flags the reference gathers in its first loop (:1255-1275) are
  * derived group by group on the way down (a group's right/below neighbours come earlier in reverse scan). */
+/* SER = 1: called by one lane (serial sections): every argument is wave-uniform */
+template <int SER>
 FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int last, int log2, int comp, int scanType, int tsFlag, const Params &P_, int16_t *absCoeff)
 {
+  if (SER) { c = FCU_UNI(c); coef = FCU_UNI(coef); last = FCU_UNI(last); scanType = FCU_UNI(scanType); tsFlag = FCU_UNI(tsFlag); absCoeff = FCU_UNI(absCoeff); }
   const Params &P = *FCU_UNI(&P_);
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp);
   FCU_IN_LDS(absCoeff);
@@ -343,6 +347,7 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
+  const uint64_t scan4 = g_hot.scan4_nib[scanType], map4 = g_hot.map4_nib;
   const int scanPosLast = last, posLast = scan[last], lastVal = coef[last * st];
   {
     int py = posLast >> log2, px = posLast - (py << log2);
@@ -376,9 +381,14 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
     }
     if ((cgflag >> cgpos) & 1) {
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
+      const uint32_t cntBits = g_hot.cnt_bits[pattern];
+      const int sigBase = baseSig + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int blk = scan[scanPosSig], v = coef[scanPosSig * st], sig = v != 0;
-        if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, baseSig + sig_ctx_inc(pattern, firstSig, blk, log2, ch));
+        const int v = coef[scanPosSig * st], sig = v != 0;
+        const int p4 = (int)((scan4 >> (4 * (scanPosSig - subPos))) & 15);     /* getSigCtxInc on the packed 4x4 scan (see rdoq) */
+        const int ctxSig = log2 == 2 ? baseSig + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0)
+                                     : (scanPosSig == 0 ? baseSig : sigBase + (int)((cntBits >> (2 * p4)) & 3));
+        if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, ctxSig);
         if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(v); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
@@ -478,10 +488,12 @@ FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *co
  * zero by construction and the consumers know topNZ.  Returns uiAbsSum and the scan position of the last
  * non-zero level (-1: none). */
 struct RdoqOut { int abs_sum, last; };
+template <int SER>
 FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
 {
   const Params &P = *FCU_UNI(&P_);
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp); cbfCtx = FCU_UNI(cbfCtx);
+  if (SER) { c = FCU_UNI(c); src = FCU_UNI(src); dst = FCU_UNI(dst); topNZ = FCU_UNI(topNZ); scanType = FCU_UNI(scanType); rec = FCU_UNI(rec); costCGSig = FCU_UNI(costCGSig); }
   if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? P.qp_c : P.qp;
@@ -500,6 +512,8 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
   int absSum = 0;
 
+  const uint64_t scan4 = g_hot.scan4_nib[scanType], map4 = g_hot.map4_nib;
+  int g10 = 0, g10Ctx = -1;
   /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order) */
   const int cgTop = topNZ >> 4;
   for (int scanPos = n2 - 1; scanPos >= (cgTop + 1) * 16; scanPos--) {
@@ -512,6 +526,15 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
     double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
     costCGSig[cgScanPos * st] = 0;
+    /* The contexts are frozen during RDOQ (estBit snapshot, TEncSbac.cpp:1722-1956), so the significance costs of a
+     * group are loop invariants: in a TU > 4x4 only the three contexts sigBase + cnt occur besides DC (sig_ctx_inc). */
+    const int sigBase = sigOff + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
+    int b00 = 0, b01 = 0, b02 = 0, b10 = 0, b11 = 0, b12 = 0;
+    if (log2 > 2) {
+      b00 = ctx_bits(c, sigBase, 0); b01 = ctx_bits(c, sigBase + 1, 0); b02 = ctx_bits(c, sigBase + 2, 0);
+      b10 = ctx_bits(c, sigBase, 1); b11 = ctx_bits(c, sigBase + 1, 1); b12 = ctx_bits(c, sigBase + 2, 1);
+    }
+    const uint32_t cntBits = g_hot.cnt_bits[pattern];
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
       const int32_t levelDouble = iabs(src[scanPos * st]);
@@ -527,25 +550,35 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         cgLastScanPos = cgScanPos;
       }
       if (lastScanPos >= 0) {
-        const int blk = scan[scanPos];
-        const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1, absCtx = CTX_ABS + (int)ctxSet + c2;
+        const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1;
+        if (oneCtx != g10Ctx) { g10 = ctx_bits(c, oneCtx, 0); g10Ctx = oneCtx; }
+        /* position inside the 4x4 group (raster) from the packed 4x4 scan; its significance context */
+        const int p4 = (int)((scan4 >> (4 * posInCG)) & 15);
+        int ctxSig, sbit0, sbit1;
+        if (log2 == 2) { ctxSig = sigOff + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0); sbit0 = ctx_bits(c, ctxSig, 0); sbit1 = ctx_bits(c, ctxSig, 1); }
+        else if (scanPos == 0) { ctxSig = sigOff; sbit0 = ctx_bits(c, ctxSig, 0); sbit1 = ctx_bits(c, ctxSig, 1); }
+        else { const int cnt = (int)((cntBits >> (2 * p4)) & 3); ctxSig = sigBase + cnt; sbit0 = cnt == 0 ? b00 : (cnt == 1 ? b01 : b02); sbit1 = cnt == 0 ? b10 : (cnt == 1 ? b11 : b12); }
         int sdel = 0, rup, rdn = 0;
-        LevelBits lb; lb.g10 = ctx_bits(c, oneCtx, 0); lb.g11 = lb.g20 = lb.g21 = 0;
-        if (maxAbsLevel > 0) { lb.g11 = ctx_bits(c, oneCtx, 1); lb.g20 = ctx_bits(c, absCtx, 0); lb.g21 = ctx_bits(c, absCtx, 1); }
-        if (scanPos == lastScanPos)
-          level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                              sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1);
-        else {
-          const int ctxSig = sigOff + sig_ctx_inc(pattern, firstSig, blk, log2, ch);
-          level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                              ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0);
-          sdel = ctx_bits(c, ctxSig, 1) - ctx_bits(c, ctxSig, 0);
+        if (maxAbsLevel == 0) {                              /* xGetCodedLevel's early exit (:2752-2760); never the last position */
+          cs = lambda * (double)sbit0; cc = c0 + cs; level = 0;
+          sdel = sbit1 - sbit0; rup = g10;
+        } else {
+          const int absCtx = CTX_ABS + (int)ctxSet + c2;
+          LevelBits lb; lb.g10 = g10; lb.g11 = ctx_bits(c, oneCtx, 1); lb.g20 = ctx_bits(c, absCtx, 0); lb.g21 = ctx_bits(c, absCtx, 1);
+          if (scanPos == lastScanPos)
+            level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+                                sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1);
+          else {
+            level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+                                ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0);
+            sdel = sbit1 - sbit0;
+          }
+          if (level > 0) {
+            const int rateNow = ic_rate(lb, level, goRice, c1Idx, c2Idx);
+            rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateNow;
+            rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateNow;
+          } else rup = lb.g10;
         }
-        if (level > 0) {
-          const int rateNow = ic_rate(lb, level, goRice, c1Idx, c2Idx);
-          rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateNow;
-          rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateNow;
-        } else rup = lb.g10;
         RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = rup; r.dn = rdn; r.sd = sdel;
         r.du = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
         rec[scanPos * st] = r;
@@ -937,7 +970,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(Env E, int c, const CuObj *cu, TU root, i
           const int16_t *buf = realCoeff ? cu->coef[comp] : E.G->qt_coef[comp][layer];
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = comp ? tu_part_c(tu) : tu.part;
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
-          code_coeff_nxn(c, buf + (comp ? tu.off_c : tu.off_y), 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn<1>(c, buf + (comp ? tu.off_c : tu.off_y), 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -982,7 +1015,7 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(Env E, int c, const CuObj *cu, TU t
     cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
   const int cbf = g_S.t_abs > 0;
   cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-  if (cbf) code_coeff_nxn(c, E.G->p_qscan, 1, g_S.t_lsp, log2, 0, coef_scan_idx(cu->intra_dir[0][part], log2, 0), cu->tskip[0][part], E.C->p, g_S.lane_abs[0]);
+  if (cbf) code_coeff_nxn<1>(c, E.G->p_qscan, 1, g_S.t_lsp, log2, 0, coef_scan_idx(cu->intra_dir[0][part], log2, 0), cu->tskip[0][part], E.C->p, g_S.lane_abs[0]);
   return cab_bits(c);
 }
 
@@ -1016,7 +1049,7 @@ FCU_DEV FCU_NOINLINE void encode_transform(Env E, int c, const CuObj *cu, int cu
           const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
           const int dir = comp ? chroma_final_mode(cu, pc) : cu->intra_dir[0][pc];
           const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
-          code_coeff_nxn(c, coef, 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+          code_coeff_nxn<1>(c, coef, 1, -1, log2, comp, coef_scan_idx(dir, log2, comp), cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
         }
         sp--; continue;
       }
@@ -1185,7 +1218,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
       FCU_TIC(t8_);
       RdoqRec *rrec = G->r_rec; double *rcg = G->r_cg;
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      const RdoqOut o = rdoq(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
+      const RdoqOut o = rdoq<1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
       g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
       E.C->n_tu_trials++;
       FCU_TOC(E, t8_, 8);
@@ -1501,7 +1534,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
       const int mode = g_S.rd_mode[lane / tsv];
       RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      const RdoqOut o = rdoq(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
+      const RdoqOut o = rdoq<0>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
       g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
       g_S.vc_dist[lane] = 0;
     }
@@ -1551,7 +1584,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
         if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
           cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn(c, G->p_qscan + vc, nvc, g_S.vc_lsp[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
+        if (cbf) code_coeff_nxn<0>(c, G->p_qscan + vc, nvc, g_S.vc_lsp[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
         g_S.vc_bits[vc] = cab_bits(c);
         cost = rd_cost(P, g_S.vc_bits[vc], g_S.vc_dist[vc]);
       }
@@ -1722,7 +1755,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(Env E, int c, const CuObj *cu, in
           if (tu.cw != 0 && ((B->cbf[k][tu.part] >> tu.tr_depth) & 1)) {
             const int log2 = ilog2(tu.cw), pc = tu_part_c(tu);
             const int fmode = mode == DM_CHROMA ? cu->intra_dir[0][pc & ~3] : mode;
-            code_coeff_nxn(c, B->coef[k] + tu.off_c, 1, -1, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
+            code_coeff_nxn<0>(c, B->coef[k] + tu.off_c, 1, -1, log2, 1 + k, coef_scan_idx(fmode, log2, 1 + k), B->tskip[k][pc], E.C->p, absbuf);
           }
         }
         if (!subdiv) { sp--; continue; }
@@ -1794,7 +1827,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
                 const int m = lane / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
-                const RdoqOut o = rdoq(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
+                const RdoqOut o = rdoq<0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
                 g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
                 g_S.vc_dist[lane] = 0;
               }
@@ -1838,12 +1871,12 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
                   const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
                   const int c0 = CAB_LANE0 + 5 + m, c1 = CAB_LANE0 + 10 + m;
                   cab_copy1(&g_S.cab[c0], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c0);
-                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn(c0, G->p_qscan + m * 2, nvc, g_S.vc_lsp[m * 2], log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
+                  if (g_S.vc_abs[m * 2] > 0) code_coeff_nxn<0>(c0, G->p_qscan + m * 2, nvc, g_S.vc_lsp[m * 2], log2, comp, coef_scan_idx(mode, log2, comp), 0, P, g_S.lane_abs[lane]);
                   const double cost0 = rd_cost(P, cab_bits(c0), d0);
                   double cost1 = FCU_MAX_DOUBLE;
                   if (g_S.vc_abs[m * 2 + 1] > 0) {
                     cab_copy1(&g_S.cab[c1], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c1);
-                    code_coeff_nxn(c1, G->p_qscan + m * 2 + 1, nvc, g_S.vc_lsp[m * 2 + 1], log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
+                    code_coeff_nxn<0>(c1, G->p_qscan + m * 2 + 1, nvc, g_S.vc_lsp[m * 2 + 1], log2, comp, coef_scan_idx(mode, log2, comp), 1, P, g_S.lane_abs[lane]);
                     cost1 = rd_cost(P, cab_bits(c1), d1);
                   }
                   if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c1]); } else cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c0]);
@@ -2068,6 +2101,20 @@ FCU_DEV void load_hot_tables()
     if (lane < 12) g_hot.scan_cg8[lane / 4][lane % 4] = k_scan_cg[k_scan_cg_off[(lane / 4) * 4 + 1] + lane % 4];
     if (lane < 16) g_hot.ctx_ind_map4x4[lane] = k_ctx_ind_map4x4[lane];
     if (lane < 32) g_hot.group_idx[lane] = k_group_idx[lane];
+    if (lane < 3) { uint64_t v = 0; for (int j = 0; j < 16; j++) v |= (uint64_t)k_scan[k_scan_off[lane * 4 + 0] + j] << (4 * j); g_hot.scan4_nib[lane] = v; }
+    if (lane == 3) { uint64_t v = 0; for (int j = 0; j < 16; j++) v |= (uint64_t)k_ctx_ind_map4x4[j] << (4 * j); g_hot.map4_nib = v; }
+    if (lane >= 4 && lane < 8) {                               /* getSigCtxInc's cnt per pattern and 4x4 raster position (TComTrQuant.cpp:2650-2690) */
+      const int pattern = lane - 4; uint32_t v = 0;
+      for (int j = 0; j < 16; j++) {
+        const int xs = j & 3, ys = j >> 2; int cnt;
+        if (pattern == 0) { const int t = xs + ys; cnt = (t >= 3) ? 0 : ((t >= 1) ? 1 : 2); }
+        else if (pattern == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
+        else if (pattern == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
+        else cnt = 2;
+        v |= (uint32_t)cnt << (2 * j);
+      }
+      g_hot.cnt_bits[pattern] = v;
+    }
   }
 }
 
