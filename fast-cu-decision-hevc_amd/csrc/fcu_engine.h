@@ -23,6 +23,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 #include "../../include/fcu.h"
 
 #ifdef FCU_EMU
@@ -833,17 +834,45 @@ FCU_DEV FCU_NOINLINE void build_ref(Env E, int comp, int px, int py, int log2, i
 /* transforms: one output coefficient per call (xTrMxN / xITrMxN, TComTrQuant.cpp:860-987;    */
 /* the partial butterflies are exact factorizations of these products)                       */
 /* ======================================================================================== */
-FCU_DEV int tmat(int log2, int useDst, int k, int n) { return (useDst && log2 == 2) ? k_dst4[k * 4 + n] : k_dct[k_dct_off[log2 - 2] + (k << log2) + n]; }
-/* stage 1: tmp[k*N+y] from resi rows ; stage 2: coef[k2*N+k1] from tmp */
-FCU_DEV int32_t fwd1(const int16_t *resi, int log2, int useDst, int idx)
-{ const int N = 1 << log2, k = idx >> log2, y = idx & (N - 1), s1 = log2 - 1; int32_t s = 0; for (int n = 0; n < N; n++) s += tmat(log2, useDst, k, n) * resi[y * N + n]; return (s + (1 << (s1 - 1))) >> s1; }
-FCU_DEV int32_t fwd2(const int32_t *tmp, int log2, int useDst, int idx)
-{ const int N = 1 << log2, k2 = idx >> log2, k1 = idx & (N - 1), s2 = log2 + 6; int32_t s = 0; for (int y = 0; y < N; y++) s += tmat(log2, useDst, k2, y) * tmp[k1 * N + y]; return (s + (1 << (s2 - 1))) >> s2; }
-/* inverse stage 1: tmp[kh*N+y] from dequantised coef ; stage 2: resi[y*N+x] */
-FCU_DEV int32_t inv1(const int32_t *coef, int log2, int useDst, int idx)
-{ const int N = 1 << log2, kh = idx >> log2, y = idx & (N - 1); int32_t s = 0; for (int kv = 0; kv < N; kv++) s += tmat(log2, useDst, kv, y) * coef[kv * N + kh]; return clip3i(-32768, 32767, (s + 64) >> 7); }
-FCU_DEV int32_t inv2(const int32_t *tmp, int log2, int useDst, int idx)
-{ const int N = 1 << log2, y = idx >> log2, x = idx & (N - 1); int32_t s = 0; for (int kh = 0; kh < N; kh++) s += tmat(log2, useDst, kh, x) * tmp[kh * N + y]; return clip3i(-32768, 32767, (s + 2048) >> 12); }
+/* Every stage is a dot product of one basis row with one CONTIGUOUS data row, unrolled per size so that the loads
+ * of a row are issued together (wide loads) instead of one dependent load per multiply-add:
+ *   fwd1: tmp[k*N + y]   = sum_n T[k][n]  * resi[y*N + n]          fwd2: coef[k2*N + k1] = sum_y T[k2][y] * tmp[k1*N + y]
+ *   inv1: tmp2[y*N + kh] = sum_kv Tt[y][kv] * deqT[kh*N + kv]      inv2: resi[y*N + x]   = sum_kh Tt[x][kh] * tmp2[y*N + kh]
+ * (Tt = transposed basis; deqT = de-quantised coefficients stored transposed by the caller, see tr_index). */
+template <int N, class T>
+FCU_DEV int32_t dot_row(const int8_t *m, const T *a)
+{
+  m = (const int8_t *)__builtin_assume_aligned(m, N >= 16 ? 16 : N);
+  a = (const T *)__builtin_assume_aligned(a, sizeof(T) * N >= 16 ? 16 : 8);
+  uint32_t mw[N / 4];                                         /* four basis values per word: N/4 (wide) loads */
+  __builtin_memcpy(mw, m, N);
+  int32_t s = 0;
+#pragma unroll
+  for (int n = 0; n < N; n++) s += (int32_t)(int8_t)(mw[n >> 2] >> (8 * (n & 3))) * (int32_t)a[n];
+  return s;
+}
+/* size dispatch OUTSIDE the element loops: f(std::integral_constant<int, log2>) */
+template <class F>
+FCU_DEV void by_log2(int log2, F f)
+{
+  switch (log2) {
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 3: f(std::integral_constant<int, 3>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    default: f(std::integral_constant<int, 5>()); break;
+  }
+}
+template <int LOG2> FCU_DEV const int8_t *basis_row(int useDst, int k) { return (useDst && LOG2 == 2) ? k_dst4 + k * 4 : k_dct + k_dct_off[LOG2 - 2] + (k << LOG2); }
+template <int LOG2> FCU_DEV const int8_t *basis_col(int useDst, int n) { return (useDst && LOG2 == 2) ? k_dst4_t + n * 4 : k_dct_t + k_dct_off[LOG2 - 2] + (n << LOG2); }
+FCU_DEV int tr_index(int i, int log2) { const int N = 1 << log2; return ((i & (N - 1)) << log2) + (i >> log2); }   /* raster index of the transposed block */
+template <int LOG2> FCU_DEV int32_t fwd1(const int16_t *resi, int useDst, int idx)
+{ constexpr int N = 1 << LOG2, s1 = LOG2 - 1; const int k = idx >> LOG2, y = idx & (N - 1); return (dot_row<N>(basis_row<LOG2>(useDst, k), resi + (y << LOG2)) + (1 << (s1 - 1))) >> s1; }
+template <int LOG2> FCU_DEV int32_t fwd2(const int32_t *tmp, int useDst, int idx)
+{ constexpr int N = 1 << LOG2, s2 = LOG2 + 6; const int k2 = idx >> LOG2, k1 = idx & (N - 1); return (dot_row<N>(basis_row<LOG2>(useDst, k2), tmp + (k1 << LOG2)) + (1 << (s2 - 1))) >> s2; }
+template <int LOG2> FCU_DEV int32_t inv1(const int32_t *deqT, int useDst, int idx)
+{ constexpr int N = 1 << LOG2; const int y = idx >> LOG2, kh = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, y), deqT + (kh << LOG2)) + 64) >> 7); }
+template <int LOG2> FCU_DEV int32_t inv2(const int32_t *tmp2, int useDst, int idx)
+{ constexpr int N = 1 << LOG2; const int y = idx >> LOG2, x = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, x), tmp2 + (y << LOG2)) + 2048) >> 12); }
 FCU_DEV int32_t dequant1(int q, int log2, int qp)          /* xDeQuant flat, TComTrQuant.cpp:1242-1352 */
 {
   const int per = qp / 6, rem = qp % 6, rs = 6 - ((15 - 8 - log2) + per), scale = k_inv_quant_scales[rem];
@@ -1209,8 +1238,8 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
   const uint16_t *iscan = k_iscan + k_scan_off[scanType * 4 + log2 - 2];
   if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } } }
   else {
-    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1(G->p_resi, log2, useDst, i); }
-    FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2(G->p_tmp, log2, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }
+    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi, useDst, i); }); }
+    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<decltype(L)::value>(G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
   }
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
@@ -1229,13 +1258,13 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
     const int np = comp ? tu_nparts_c(tu) : tu.nparts;
     for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
     const int cgEnd = ((g_S.t_last >> 4) + 1) << 4;                /* RDOQ wrote the levels of scan positions < cgEnd */
-    for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int q = (absSum > 0 && sp < cgEnd) ? G->p_qscan[sp] : 0; coef[sp] = (int16_t)q; G->p_tmp[i] = dequant1(q, log2, qp); }
+    for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int q = (absSum > 0 && sp < cgEnd) ? G->p_qscan[sp] : 0; coef[sp] = (int16_t)q; G->p_tmp[useTS ? i : tr_index(i, log2)] = dequant1(q, log2, qp); }
   }
   if (absSum > 0) {
     if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
     else {
-      FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = inv1(G->p_tmp, log2, useDst, i); }
-      FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)inv2(G->p_tcoef, log2, useDst, i); }
+      FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp, useDst, i); }); }
+      FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)inv2<decltype(L)::value>(G->p_tcoef, useDst, i); }); }
     }
   }
   FCU_FOR_LANES {
@@ -1517,16 +1546,18 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
       G->p_pred[i] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * 64 + x] - v);
     }
   }
-  FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1(G->p_resi + cnd * n2, log2, useDst, i - cnd * n2); } }
+  FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + cnd * n2, useDst, i - cnd * n2); } }); }
   FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
-    for (int i = lane; i < nvc * n2; i += 64) {
-      const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
-      const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
-      const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + cnd * n2, log2, useDst, p);
-      const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
-      G->p_lscan[sp * nvc + v] = ld;
-      if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
-    }
+    by_log2(log2, [&](auto L) {
+      for (int i = lane; i < nvc * n2; i += 64) {
+        const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
+        const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
+        const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + cnd * n2, useDst, p);
+        const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
+        G->p_lscan[sp * nvc + v] = ld;
+        if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
+      }
+    });
   }
   FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
@@ -1547,26 +1578,30 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
       const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v / tsv], log2, 0) * 4 + log2 - 2];
       const int sp = iscan[p];
       const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-      G->p_tmp[i] = dequant1(q, log2, P.qp);
+      G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, log2, P.qp);
     }
   }
   FCU_FOR_LANES {
-    for (int i = lane; i < nvc * n2; i += 64) {
-      const int v = i / n2, p = i - v * n2, ts = v % tsv;
-      if (ts) { const int s = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (s - 1))) >> s; }
-      else G->p_tcoef[i] = inv1(G->p_tmp + v * n2, log2, useDst, p);
-    }
+    by_log2(log2, [&](auto L) {
+      for (int i = lane; i < nvc * n2; i += 64) {
+        const int v = i / n2, p = i - v * n2, ts = v % tsv;
+        if (ts) { const int s = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (s - 1))) >> s; }
+        else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, useDst, p);
+      }
+    });
   }
   FCU_FOR_LANES {
-    for (int i = lane; i < nvc * n2; i += 64) {
-      const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
-      int res = 0;
-      if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, useDst, p);
-      const int r = clip8(G->p_pred[cnd * n2 + p] + res);
-      G->p_rec[i] = (uint8_t)r;
-      const int e = org[y * 64 + x] - r;
-      FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
-    }
+    by_log2(log2, [&](auto L) {
+      for (int i = lane; i < nvc * n2; i += 64) {
+        const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+        int res = 0;
+        if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2<decltype(L)::value>(G->p_tcoef + v * n2, useDst, p);
+        const int r = clip8(G->p_pred[cnd * n2 + p] + res);
+        G->p_rec[i] = (uint8_t)r;
+        const int e = org[y * 64 + x] - r;
+        FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+      }
+    });
   }
   FCU_TIC(t3_);
   FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
@@ -1809,17 +1844,19 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
                 G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
               }
             }
-            FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1(G->p_resi + m * n2, log2, 0, i - m * n2); } }
+            FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + m * n2, 0, i - m * n2); } }); }
             FCU_FOR_LANES {
-              for (int i = lane; i < nvc * n2; i += 64) {
-                const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
-                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
-                const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
-                const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2(G->p_tmp + m * n2, log2, 0, p);
-                const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
-                G->p_lscan[sp * nvc + v] = ld;
-                if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
-              }
+              by_log2(log2, [&](auto L) {
+                for (int i = lane; i < nvc * n2; i += 64) {
+                  const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
+                  const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                  const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
+                  const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + m * n2, 0, p);
+                  const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
+                  G->p_lscan[sp * nvc + v] = ld;
+                  if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
+                }
+              });
             }
             FCU_TIC(t13_);
             FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
@@ -1841,26 +1878,30 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
                 const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
                 const int sp = iscan[p];
                 const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-                G->p_tmp[i] = dequant1(q, log2, P.qp_c);
+                G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, log2, P.qp_c);
               }
             }
             FCU_FOR_LANES {
-              for (int i = lane; i < nvc * n2; i += 64) {
-                const int v = i / n2, p = i - v * n2, ts = v % tsv;
-                if (ts) { const int sft = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (sft - 1))) >> sft; }
-                else G->p_tcoef[i] = inv1(G->p_tmp + v * n2, log2, 0, p);
-              }
+              by_log2(log2, [&](auto L) {
+                for (int i = lane; i < nvc * n2; i += 64) {
+                  const int v = i / n2, p = i - v * n2, ts = v % tsv;
+                  if (ts) { const int sft = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (sft - 1))) >> sft; }
+                  else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, 0, p);
+                }
+              });
             }
             FCU_FOR_LANES {
-              for (int i = lane; i < nvc * n2; i += 64) {
-                const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
-                int res = 0;
-                if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2(G->p_tcoef + v * n2, log2, 0, p);
-                const int r = clip8(G->p_pred[m * n2 + p] + res);
-                G->p_rec[i] = (uint8_t)r;
-                const int e = org[y * 32 + x] - r;
-                FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
-              }
+              by_log2(log2, [&](auto L) {
+                for (int i = lane; i < nvc * n2; i += 64) {
+                  const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+                  int res = 0;
+                  if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2<decltype(L)::value>(G->p_tcoef + v * n2, 0, p);
+                  const int r = clip8(G->p_pred[m * n2 + p] + res);
+                  G->p_rec[i] = (uint8_t)r;
+                  const int e = org[y * 32 + x] - r;
+                  FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+                }
+              });
             }
             FCU_FOR_LANES {                                      /* per mode: transform-skip decision (TEncSearch.cpp:1985-2058) */
               if (lane < 5) {
