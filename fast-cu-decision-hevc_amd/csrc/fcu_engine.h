@@ -38,6 +38,7 @@
 #define FCU_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
 #define FCU_IN_LDS(p) do { } while (0)
 #define FCU_UNI(x) (x)
+#define FCU_HBM
 #define FCU_FLOOR(x) floor(x)
 #define FCU_CHECK(c) do { if (!(c)) { fprintf(stderr, "FCU_CHECK failed: %s (line %d)\n", #c, __LINE__); abort(); } } while (0)
 #else
@@ -61,6 +62,13 @@ template <class T> __device__ inline T fcu_uni(T v)
   return v;
 }
 #define FCU_UNI(x) fcu_uni(x)
+/* pointer-to-HBM type qualifier: accesses become global_ instead of flat_ instructions, which (unlike flat) may stay
+ * in flight across a partial s_waitcnt -- needed for the one-ahead loads of the serial coefficient loops */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FCU_HBM __attribute__((address_space(1)))
+#else
+#define FCU_HBM
+#endif
 #define FCU_GENERIC_(p) ((const __attribute__((address_space(0))) void *)(p))
 #define FCU_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared(FCU_GENERIC_(p)))
 #define FCU_FLOOR(x) floor(x)
@@ -71,9 +79,11 @@ template <class T> __device__ inline T fcu_uni(T v)
 #if defined(FCU_PROFILE) && !defined(FCU_EMU)
 #define FCU_TIC(v) const long long v = clock64()
 #define FCU_TOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#define FCU_COUNT(E_, idx, n) do { (E_).C->prof[idx] += (unsigned long long)(n); } while (0)
 #else
 #define FCU_TIC(v) do { } while (0)
 #define FCU_TOC(E_, v, idx) do { } while (0)
+#define FCU_COUNT(E_, idx, n) do { } while (0)
 #endif
 
 #include "fcu_tables.h"
@@ -341,15 +351,16 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
   const Params &P = *FCU_UNI(&P_);
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp);
   FCU_IN_LDS(absCoeff);
+  const FCU_HBM int16_t *coefg = (const FCU_HBM int16_t *)coef;
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
-  if (last < 0) { last = n2 - 1; while (last >= 0 && coef[last * st] == 0) last--; if (last < 0) return; }
+  if (last < 0) { last = n2 - 1; while (last >= 0 && coefg[last * st] == 0) last--; if (last < 0) return; }
   if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
   const uint64_t scan4 = g_hot.scan4_nib[scanType], map4 = g_hot.map4_nib;
-  const int scanPosLast = last, posLast = scan[last], lastVal = coef[last * st];
+  const int scanPosLast = last, posLast = scan[last], lastVal = coefg[last * st];
   {
     int py = posLast >> log2, px = posLast - (py << log2);
     if (scanType == 2) { int t = px; px = py; py = t; }
@@ -376,7 +387,7 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
     if (sub == lastSet || sub == 0) cgflag |= 1ull << cgpos;
     else {
       int any = 0;
-      for (int k = 0; k < 16; k++) any |= coef[(subPos + k) * st];
+      for (int k = 0; k < 16; k++) any |= coefg[(subPos + k) * st];
       if (any) cgflag |= 1ull << cgpos;
       cab_bin(c, any != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
     }
@@ -384,8 +395,10 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       const uint32_t cntBits = g_hot.cnt_bits[pattern];
       const int sigBase = baseSig + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
+      int ahead = scanPosSig >= subPos ? coefg[scanPosSig * st] : 0;
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int v = coef[scanPosSig * st], sig = v != 0;
+        const int v = ahead, sig = v != 0;
+        if (scanPosSig > subPos) ahead = coefg[(scanPosSig - 1) * st];       /* one ahead */
         const int p4 = (int)((scan4 >> (4 * (scanPosSig - subPos))) & 15);     /* getSigCtxInc on the packed 4x4 scan (see rdoq) */
         const int ctxSig = log2 == 2 ? baseSig + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0)
                                      : (scanPosSig == 0 ? baseSig : sigBase + (int)((cntBits >> (2 * p4)) & 3));
@@ -496,6 +509,8 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp); cbfCtx = FCU_UNI(cbfCtx);
   if (SER) { c = FCU_UNI(c); src = FCU_UNI(src); dst = FCU_UNI(dst); topNZ = FCU_UNI(topNZ); scanType = FCU_UNI(scanType); rec = FCU_UNI(rec); costCGSig = FCU_UNI(costCGSig); }
   if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
+  const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
+  FCU_HBM RdoqRec *recg = (FCU_HBM RdoqRec *)rec; FCU_HBM double *cgg = (FCU_HBM double *)costCGSig;
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? P.qp_c : P.qp;
   const int qbits = rdoq_qbits(log2, qp);
@@ -518,15 +533,16 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order) */
   const int cgTop = topNZ >> 4;
   for (int scanPos = n2 - 1; scanPos >= (cgTop + 1) * 16; scanPos--) {
-    const double err = (double)iabs(src[scanPos * st]);
+    const double err = (double)iabs(srcg[scanPos * st]);
     blockUncodedCost += err * err * errScale;
   }
   baseCost = blockUncodedCost;
+  int32_t ahead = srcg[(cgTop * 16 + 15) * st];
   for (int cgScanPos = cgTop; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
     double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
-    costCGSig[cgScanPos * st] = 0;
+    cgg[cgScanPos * st] = 0;
     /* The contexts are frozen during RDOQ (estBit snapshot, TEncSbac.cpp:1722-1956), so the significance costs of a
      * group are loop invariants: in a TU > 4x4 only the three contexts sigBase + cnt occur besides DC (sig_ctx_inc). */
     const int sigBase = sigOff + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
@@ -538,7 +554,8 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
     const uint32_t cntBits = g_hot.cnt_bits[pattern];
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
-      const int32_t levelDouble = iabs(src[scanPos * st]);
+      const int32_t levelDouble = iabs(ahead);
+      if (scanPos > 0) ahead = srcg[(scanPos - 1) * st];      /* one ahead: its latency overlaps this coefficient's work */
       uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
       if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
       const double err = (double)levelDouble;
@@ -561,8 +578,16 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         else { const int cnt = (int)((cntBits >> (2 * p4)) & 3); ctxSig = sigBase + cnt; sbit0 = cnt == 0 ? b00 : (cnt == 1 ? b01 : b02); sbit1 = cnt == 0 ? b10 : (cnt == 1 ? b11 : b12); }
         int sdel = 0, rup, rdn = 0;
         if (maxAbsLevel == 0) {                              /* xGetCodedLevel's early exit (:2752-2760); never the last position */
-          cs = lambda * (double)sbit0; cc = c0 + cs; level = 0;
-          sdel = sbit1 - sbit0; rup = g10;
+          /* short path: level 0 leaves c1/c2/Rice state alone; everything the long path does for it, and on to the next */
+          cs = lambda * (double)sbit0; cc = c0 + cs;
+          RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = g10; r.dn = 0; r.sd = sbit1 - sbit0;
+          r.du = (int32_t)(levelDouble >> (qbits - 8));
+          recg[scanPos * st] = r;
+          baseCost += cc;
+          dstg[scanPos * st] = 0;
+          rdSigCost += cs;
+          if (posInCG == 0) rdSigCost0 = cs;
+          continue;
         } else {
           const int absCtx = CTX_ABS + (int)ctxSet + c2;
           LevelBits lb; lb.g10 = g10; lb.g11 = ctx_bits(c, oneCtx, 1); lb.g20 = ctx_bits(c, absCtx, 0); lb.g21 = ctx_bits(c, absCtx, 1);
@@ -582,19 +607,15 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         }
         RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = rup; r.dn = rdn; r.sd = sdel;
         r.du = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
-        rec[scanPos * st] = r;
+        recg[scanPos * st] = r;
         baseCost += cc;
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
         if (level >= 1) c1Idx++;
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
-        if ((scanPos % 16 == 0) && scanPos > 0) {
-          ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && ((scanPos - 1) >> 4) > 0) ? 2 : 0) + (c1 == 0));
-          c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
-        }
       } else baseCost += c0;
-      dst[scanPos * st] = (int16_t)level;
+      dstg[scanPos * st] = (int16_t)level;
       rdSigCost += cs;
       if (posInCG == 0) rdSigCost0 = cs;
       if (level) {
@@ -604,26 +625,30 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         if (posInCG != 0) nnzBeforePos0++;
       }
     }
+    if (lastScanPos >= 0 && cgScanPos > 0) {                 /* context set of the next group (:2306-2316), once the last position is known */
+      ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && (cgScanPos - 1) > 0) ? 2 : 0) + (c1 == 0));
+      c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+    }
     if (cgLastScanPos >= 0) {
       if (cgScanPos) {
         if (((cgflag >> cgBlk) & 1) == 0) {
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
           baseCost += lambda * (double)ctx_bits(c, ctxSig, 0) - rdSigCost;
-          costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
+          cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
         } else if (cgScanPos < cgLastScanPos) {
           if (nnzBeforePos0 == 0) { baseCost -= rdSigCost0; rdSigCost -= rdSigCost0; }
           double costZeroCG = baseCost;
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
           baseCost += lambda * (double)ctx_bits(c, ctxSig, 1);
           costZeroCG += lambda * (double)ctx_bits(c, ctxSig, 0);
-          costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 1);
+          cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 1);
           costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
           if (costZeroCG < baseCost) {
             cgflag &= ~(1ull << cgBlk); baseCost = costZeroCG;
-            costCGSig[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
+            cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
             for (int posInCG = 15; posInCG >= 0; posInCG--) {
               const int scanPos = cgScanPos * 16 + posInCG;
-              if (dst[scanPos * st]) { dst[scanPos * st] = 0; rec[scanPos * st].cc = rec[scanPos * st].c0; rec[scanPos * st].cs = 0; }
+              if (dstg[scanPos * st]) { dstg[scanPos * st] = 0; recg[scanPos * st].cc = recg[scanPos * st].c0; recg[scanPos * st].cs = 0; }
             }
           }
         }
@@ -641,12 +666,12 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   int foundLast = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos];
-    baseCost -= costCGSig[cgScanPos * st];
+    baseCost -= cgg[cgScanPos * st];
     if ((cgflag >> cgBlk) & 1) {
       for (int posInCG = 15; posInCG >= 0; posInCG--) {
         const int scanPos = cgScanPos * 16 + posInCG;
         if (scanPos > lastScanPos) continue;
-        const int lv = dst[scanPos * st];
+        const int lv = dstg[scanPos * st];
         if (lv) {
           const int blk = scan[scanPos];
           const int py = blk >> log2, px = blk - (py << log2);
@@ -661,38 +686,38 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
           if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
           const double costLast = lambda * r;
-          const double totalCost = baseCost + costLast - rec[scanPos * st].cs;
+          const double totalCost = baseCost + costLast - recg[scanPos * st].cs;
           if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
           if (lv > 1) { foundLast = 1; break; }
-          baseCost -= rec[scanPos * st].cc; baseCost += rec[scanPos * st].c0;
-        } else baseCost -= rec[scanPos * st].cs;
+          baseCost -= recg[scanPos * st].cc; baseCost += recg[scanPos * st].c0;
+        } else baseCost -= recg[scanPos * st].cs;
       }
       if (foundLast) break;
     }
   }
   for (int sp = 0; sp < bestLastIdxP1; sp++) {
-    const int level = dst[sp * st];
+    const int level = dstg[sp * st];
     absSum += level;
-    dst[sp * st] = (int16_t)((src[sp * st] < 0) ? -level : level);
+    dstg[sp * st] = (int16_t)((srcg[sp * st] < 0) ? -level : level);
   }
-  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[sp * st] = 0;
+  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
 
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
     for (int subSet = cgTop; subSet >= 0; subSet--) {            /* groups above hold no level */
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
-      for (n = 15; n >= 0; --n) if (dst[(n + subPos) * st]) { lastNZ = n; break; }
-      for (n = 0; n < 16; n++) if (dst[(n + subPos) * st]) { firstNZ = n; break; }
-      for (n = firstNZ; n <= lastNZ; n++) sum += dst[(n + subPos) * st];
+      for (n = 15; n >= 0; --n) if (dstg[(n + subPos) * st]) { lastNZ = n; break; }
+      for (n = 0; n < 16; n++) if (dstg[(n + subPos) * st]) { firstNZ = n; break; }
+      for (n = firstNZ; n <= lastNZ; n++) sum += dstg[(n + subPos) * st];
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = dst[(subPos + firstNZ) * st] > 0 ? 0 : 1;
+        const uint32_t signbit = dstg[(subPos + firstNZ) * st] > 0 ? 0 : 1;
         if (signbit != (uint32_t)(sum & 1)) {
           long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
           int minPos = -1, finalChange = 0, curChange = 0;
           for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
-            const int sp = n + subPos; const int lv = dst[sp * st]; const RdoqRec &q = rec[sp * st];
+            const int sp = n + subPos; const int lv = dstg[sp * st]; const RdoqRec q = recg[sp * st];
             if (lv != 0) {
               const long long costUp = rdFactor * (-q.du) + q.up;
               long long costDown = rdFactor * (q.du) + q.dn - ((iabs(lv) == 1) ? q.sd : 0);
@@ -702,21 +727,21 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
             } else {
               curCost = rdFactor * (-(long long)(iabs(q.du))) + (1 << 15) + q.up + q.sd;
               curChange = 1;
-              if (n < firstNZ) { const uint32_t thissign = src[sp * st] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
+              if (n < firstNZ) { const uint32_t thissign = srcg[sp * st] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
             }
             if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = sp; }
           }
-          const int old = dst[minPos * st];
+          const int old = dstg[minPos * st];
           if (old == 32767 || old == -32768) finalChange = -1;
-          const int nv = src[minPos * st] >= 0 ? old + finalChange : old - finalChange;
-          dst[minPos * st] = (int16_t)nv;
+          const int nv = srcg[minPos * st] >= 0 ? old + finalChange : old - finalChange;
+          dstg[minPos * st] = (int16_t)nv;
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
   int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
-  while (last >= 0 && dst[last * st] == 0) last--;
+  while (last >= 0 && dstg[last * st] == 0) last--;
   RdoqOut o = { absSum, last };
   return o;
 }
@@ -1250,6 +1275,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
       const RdoqOut o = rdoq<1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
       g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
       E.C->n_tu_trials++;
+      FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */
       FCU_TOC(E, t8_, 8);
     }
   }

@@ -27,8 +27,13 @@ print('chains',frames*4,'ctus',nct,'time',dt,'CTU/s',frames*4*nct/dt)
 names=['rmd','pass1_total','pass1_rdoq','pass1_bits','pass2_rqt','chroma_batched','chroma_total','cu_syntax','seq_rdoq','replay','ctu_total','tu_trial_total','rqt_bits_walk','chroma_rdoq','chroma_tree_bits']
 import numpy as np
 acc=np.zeros(17)
+packed=0
 for c in range(0,frames*4,max(1,frames*4//64)):
-    acc+=np.array(eng.debug_counters(c),dtype=float)
+    dc=eng.debug_counters(c)
+    packed+=int(dc[15])
+    acc+=np.array(dc,dtype=float)
 tot=acc[10]
 for i,n in enumerate(names): print('%-16s %6.2f%%'%(n,100*acc[i]/tot))
+n=len(range(0,frames*4,max(1,frames*4//64)))*nct
+print('seq rdoq calls/CTU', (packed>>40)/n, 'active coefficient iterations/CTU', (packed & ((1<<40)-1))/n)
 print('tu trials/CTU', acc[16]/ (len(range(0,frames*4,max(1,frames*4//64)))*nct))
