@@ -353,7 +353,15 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
   FCU_IN_LDS(absCoeff);
   const FCU_HBM int16_t *coefg = (const FCU_HBM int16_t *)coef;
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
-  if (last < 0) { last = n2 - 1; while (last >= 0 && coefg[last * st] == 0) last--; if (last < 0) return; }
+  if (last < 0) {                                             /* find the last non-zero level, a group's sixteen loads at a time */
+    for (int cg = (n2 >> 4) - 1; cg >= 0 && last < 0; cg--) {
+      uint32_t nz = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) nz |= (uint32_t)(coefg[(cg * 16 + k) * st] != 0) << k;
+      if (nz) last = cg * 16 + 31 - __builtin_clz(nz);
+    }
+    if (last < 0) return;
+  }
   if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
@@ -532,9 +540,12 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   int g10 = 0, g10Ctx = -1;
   /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order) */
   const int cgTop = topNZ >> 4;
-  for (int scanPos = n2 - 1; scanPos >= (cgTop + 1) * 16; scanPos--) {
-    const double err = (double)iabs(srcg[scanPos * st]);
-    blockUncodedCost += err * err * errScale;
+  for (int cg = (n2 >> 4) - 1; cg > cgTop; cg--) {              /* a group's sixteen loads first, then the adds in scan order */
+    int32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = srcg[(cg * 16 + k) * st];
+#pragma unroll
+    for (int k = 15; k >= 0; k--) { const double err = (double)iabs(v[k]); blockUncodedCost += err * err * errScale; }
   }
   baseCost = blockUncodedCost;
   int32_t ahead = srcg[(cgTop * 16 + 15) * st];
@@ -668,10 +679,12 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
     const int cgBlk = scanCG[cgScanPos];
     baseCost -= cgg[cgScanPos * st];
     if ((cgflag >> cgBlk) & 1) {
-      for (int posInCG = 15; posInCG >= 0; posInCG--) {
+      const int top = (cgScanPos * 16 + 15 > lastScanPos) ? lastScanPos - cgScanPos * 16 : 15;   /* positions above the last one are skipped */
+      int aLv = dstg[(cgScanPos * 16 + top) * st]; double aCs = recg[(cgScanPos * 16 + top) * st].cs;    /* one ahead */
+      for (int posInCG = top; posInCG >= 0; posInCG--) {
         const int scanPos = cgScanPos * 16 + posInCG;
-        if (scanPos > lastScanPos) continue;
-        const int lv = dstg[scanPos * st];
+        const int lv = aLv; const double curCs = aCs;
+        if (posInCG > 0) { aLv = dstg[(scanPos - 1) * st]; aCs = recg[(scanPos - 1) * st].cs; }
         if (lv) {
           const int blk = scan[scanPos];
           const int py = blk >> log2, px = blk - (py << log2);
@@ -686,33 +699,43 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
           if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
           const double costLast = lambda * r;
-          const double totalCost = baseCost + costLast - recg[scanPos * st].cs;
+          const double totalCost = baseCost + costLast - curCs;
           if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
           if (lv > 1) { foundLast = 1; break; }
           baseCost -= recg[scanPos * st].cc; baseCost += recg[scanPos * st].c0;
-        } else baseCost -= recg[scanPos * st].cs;
+        } else baseCost -= curCs;
       }
       if (foundLast) break;
     }
   }
-  for (int sp = 0; sp < bestLastIdxP1; sp++) {
-    const int level = dstg[sp * st];
-    absSum += level;
-    dstg[sp * st] = (int16_t)((srcg[sp * st] < 0) ? -level : level);
+  {
+    int aL = bestLastIdxP1 > 0 ? dstg[0] : 0; int32_t aS = bestLastIdxP1 > 0 ? srcg[0] : 0;           /* one ahead */
+    for (int sp = 0; sp < bestLastIdxP1; sp++) {
+      const int level = aL; const int32_t sv = aS;
+      if (sp + 1 < bestLastIdxP1) { aL = dstg[(sp + 1) * st]; aS = srcg[(sp + 1) * st]; }
+      absSum += level;
+      dstg[sp * st] = (int16_t)((sv < 0) ? -level : level);
+    }
   }
   for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
 
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
-    for (int subSet = cgTop; subSet >= 0; subSet--) {            /* groups above hold no level */
+    for (int subSet = (bestLastIdxP1 - 1) >> 4; subSet >= 0; subSet--) {   /* groups above hold no level any more */
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
-      for (n = 15; n >= 0; --n) if (dstg[(n + subPos) * st]) { lastNZ = n; break; }
-      for (n = 0; n < 16; n++) if (dstg[(n + subPos) * st]) { firstNZ = n; break; }
-      for (n = firstNZ; n <= lastNZ; n++) sum += dstg[(n + subPos) * st];
+      uint32_t nzMask = 0, negMask = 0;                          /* the group's sixteen levels in one go */
+      {
+        int lv16[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) lv16[k] = dstg[(subPos + k) * st];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { sum += lv16[k]; nzMask |= (uint32_t)(lv16[k] != 0) << k; negMask |= (uint32_t)(lv16[k] < 0) << k; }
+      }
+      if (nzMask) { lastNZ = 31 - __builtin_clz(nzMask); firstNZ = __builtin_ctz(nzMask); }
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = dstg[(subPos + firstNZ) * st] > 0 ? 0 : 1;
+        const uint32_t signbit = (negMask >> firstNZ) & 1;
         if (signbit != (uint32_t)(sum & 1)) {
           long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
           int minPos = -1, finalChange = 0, curChange = 0;
