@@ -78,8 +78,13 @@ template <class T> __device__ inline T fcu_uni(T v)
 /* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
 #if defined(FCU_PROFILE) && !defined(FCU_EMU)
 #define FCU_TIC(v) const long long v = clock64()
+#ifdef FCU_PROFILE_RDOQ   /* slots 11..15 belong to the sub-timers inside the serial RDOQ in this variant */
+#define FCU_TOC(E_, v, idx) do { if ((idx) < 11 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#define FCU_COUNT(E_, idx, n) do { } while (0)
+#else
 #define FCU_TOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_COUNT(E_, idx, n) do { (E_).C->prof[idx] += (unsigned long long)(n); } while (0)
+#endif
 #else
 #define FCU_TIC(v) do { } while (0)
 #define FCU_TOC(E_, v, idx) do { } while (0)
@@ -98,6 +103,13 @@ static HotTables g_hot;
 __shared__ HotTables g_hot;
 #endif
 
+#if defined(FCU_PROFILE_RDOQ) && !defined(FCU_EMU)
+#define FCU_RTIC(v) long long v = clock64()
+#define FCU_RTOC(P_, v, idx) do { if (SER) { ((Chain *)((char *)&(P_) - __builtin_offsetof(Chain, p)))->prof[idx] += (unsigned long long)(clock64() - v); v = clock64(); } } while (0)
+#else
+#define FCU_RTIC(v) do { } while (0)
+#define FCU_RTOC(P_, v, idx) do { } while (0)
+#endif
 namespace fcu {
 
 /* ---- constants ------------------------------------------------------------------------ */
@@ -180,7 +192,9 @@ struct Shared {
   union {                                           /* never live at the same time */
     int16_t lane_abs[MAXVC][16];                    /* per-lane |level| list of the coefficient group being coded */
     int32_t colsum[128];                            /* SATD column sums / availability flags of build_ref */
+    RdoqRec rq_rec[16];                             /* serial RDOQ: records of the coefficient group in flight */
   };
+  int16_t rq_lv[16];                                /* serial RDOQ: levels of the coefficient group in flight */
   int16_t diff[DIFFN];
   uint32_t sad[36];
   int dc;
@@ -326,16 +340,14 @@ FCU_DEV int sig_ctx_inc(int pattern, int first, int pos, int log2, int ch)     /
   }
   return first + offset;
 }
-FCU_DEV void code_coef_remain(int c, uint32_t symbol, uint32_t rparam)      /* TEncSbac.cpp:338-391 */
+FCU_DEV int coef_remain_bins(uint32_t symbol, uint32_t rparam)             /* bypass bins of xWriteCoefRemainExGolomb, TEncSbac.cpp:338-391 */
 {
   int code = (int)symbol;
-  if (code < (3 << rparam)) { cab_ep(c, (int)(((uint32_t)code >> rparam) + 1)); cab_ep(c, (int)rparam); }
-  else {
-    uint32_t length = rparam;
-    code -= 3 << rparam;
-    while (code >= (1 << length)) code -= 1 << (length++);
-    cab_ep(c, (int)(3 + length + 1 - rparam)); cab_ep(c, (int)length);
-  }
+  if (code < (3 << rparam)) return (int)(((uint32_t)code >> rparam) + 1) + (int)rparam;
+  uint32_t length = rparam;
+  code -= 3 << rparam;
+  while (code >= (1 << length)) code -= 1 << (length++);
+  return (int)(3 + length + 1 - rparam) + (int)length;
 }
 /* TEncSbac::codeCoeffNxN (+codeTransformSkipFlags, codeLastSignificantXY), TEncSbac.cpp:997-1535.
  * Inside the engine the levels of a TU are kept in SCAN ORDER (coef[sp * st] = level at scan position sp;
@@ -362,7 +374,11 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
     }
     if (last < 0) return;
   }
-  if (P.transform_skip && log2 == 2) cab_bin(c, tsFlag, CTX_TSKIP + ch);
+  /* bit/bin totals are kept in registers and added to the coder once at the end (sums commute) */
+  uint64_t fr = 0; uint32_t nb = 0;
+#define FCU_BIN(bin_, ctx_) do { const int cx_ = (ctx_); const uint32_t e_ = g_hot.bin[g_S.cab[c].ctx[cx_] * 2 + (bin_)]; nb++; fr += (uint64_t)(e_ >> 8); g_S.cab[c].ctx[cx_] = (uint8_t)e_; } while (0)
+#define FCU_EP(n_) do { const uint32_t n__ = (uint32_t)(n_); nb += n__; fr += (uint64_t)32768 * (uint64_t)n__; } while (0)
+  if (P.transform_skip && log2 == 2) FCU_BIN(tsFlag, CTX_TSKIP + ch);
   const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
@@ -376,12 +392,12 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
     const int off = ch ? 0 : (cc * 3 + ((cc + 1) >> 2)), sh = ch ? cc : ((cc + 3) >> 2);
     const int bx = CTX_LASTX + (ch ? 15 : 0) + off, by = CTX_LASTY + (ch ? 15 : 0) + off, gmax = g_hot.group_idx[N - 1];
     int k;
-    for (k = 0; k < gx; k++) cab_bin(c, 1, bx + (k >> sh));
-    if (gx < gmax) cab_bin(c, 0, bx + (k >> sh));
-    for (k = 0; k < gy; k++) cab_bin(c, 1, by + (k >> sh));
-    if (gy < gmax) cab_bin(c, 0, by + (k >> sh));
-    if (gx > 3) cab_ep(c, (gx - 2) >> 1);
-    if (gy > 3) cab_ep(c, (gy - 2) >> 1);
+    for (k = 0; k < gx; k++) FCU_BIN(1, bx + (k >> sh));
+    if (gx < gmax) FCU_BIN(0, bx + (k >> sh));
+    for (k = 0; k < gy; k++) FCU_BIN(1, by + (k >> sh));
+    if (gy < gmax) FCU_BIN(0, by + (k >> sh));
+    if (gx > 3) FCU_EP((gx - 2) >> 1);
+    if (gy > 3) FCU_EP((gy - 2) >> 1);
   }
   const int baseCG = CTX_SIGCG + (ch ? 2 : 0), baseSig = CTX_SIG + (ch ? 28 : 0), lastSet = scanPosLast >> 4;
   uint32_t c1 = 1, goRice;
@@ -397,22 +413,33 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
       int any = 0;
       for (int k = 0; k < 16; k++) any |= coefg[(subPos + k) * st];
       if (any) cgflag |= 1ull << cgpos;
-      cab_bin(c, any != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
+      FCU_BIN(any != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
     }
     if ((cgflag >> cgpos) & 1) {
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       const uint32_t cntBits = g_hot.cnt_bits[pattern];
       const int sigBase = baseSig + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
       int ahead = scanPosSig >= subPos ? coefg[scanPosSig * st] : 0;
+      /* a group of a TU > 4x4 uses three significance contexts (+ DC): their states stay in registers for the group */
+      uint32_t s0 = 0, s1 = 0, s2 = 0;
+      if (log2 > 2) { s0 = g_S.cab[c].ctx[sigBase]; s1 = g_S.cab[c].ctx[sigBase + 1]; s2 = g_S.cab[c].ctx[sigBase + 2]; }
       for (; scanPosSig >= subPos; scanPosSig--) {
         const int v = ahead, sig = v != 0;
         if (scanPosSig > subPos) ahead = coefg[(scanPosSig - 1) * st];       /* one ahead */
         const int p4 = (int)((scan4 >> (4 * (scanPosSig - subPos))) & 15);     /* getSigCtxInc on the packed 4x4 scan (see rdoq) */
-        const int ctxSig = log2 == 2 ? baseSig + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0)
-                                     : (scanPosSig == 0 ? baseSig : sigBase + (int)((cntBits >> (2 * p4)) & 3));
-        if (scanPosSig > subPos || sub == 0 || numNonZero) cab_bin(c, sig, ctxSig);
+        if (scanPosSig > subPos || sub == 0 || numNonZero) {
+          if (log2 == 2) FCU_BIN(sig, baseSig + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0));
+          else if (scanPosSig == 0) FCU_BIN(sig, baseSig);
+          else {
+            const int cnt = (int)((cntBits >> (2 * p4)) & 3);
+            const uint32_t e = g_hot.bin[(cnt == 0 ? s0 : (cnt == 1 ? s1 : s2)) * 2 + sig], ns = e & 255;
+            nb++; fr += (uint64_t)(e >> 8);
+            if (cnt == 0) s0 = ns; else if (cnt == 1) s1 = ns; else s2 = ns;
+          }
+        }
         if (sig) { absCoeff[numNonZero++] = (int16_t)iabs(v); if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
+      if (log2 > 2) { g_S.cab[c].ctx[sigBase] = (uint8_t)s0; g_S.cab[c].ctx[sigBase + 1] = (uint8_t)s1; g_S.cab[c].ctx[sigBase + 2] = (uint8_t)s2; }
     } else scanPosSig = subPos - 1;
     if (numNonZero > 0) {
       const int signHidden = (lastNZ - firstNZ >= 4);
@@ -422,25 +449,28 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
       int firstC2 = -1;
       for (int idx = 0; idx < numC1; idx++) {
         const int sym = absCoeff[idx] > 1;
-        cab_bin(c, sym, baseOne + (int)c1);
+        FCU_BIN(sym, baseOne + (int)c1);
         if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; cab_bin(c, sym, CTX_ABS + ctxSet); if (sym) escape = 1; }
+      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; FCU_BIN(sym, CTX_ABS + ctxSet); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
-      cab_ep(c, (P.sign_hiding && signHidden) ? numNonZero - 1 : numNonZero);
+      FCU_EP((P.sign_hiding && signHidden) ? numNonZero - 1 : numNonZero);
       int firstCoeff2 = 1;
       if (escape)
         for (int idx = 0; idx < numNonZero; idx++) {
           const int base = (idx < 8) ? (2 + firstCoeff2) : 1;
           if (absCoeff[idx] >= base) {
-            code_coef_remain(c, (uint32_t)(absCoeff[idx] - base), goRice);
+            FCU_EP(coef_remain_bins((uint32_t)(absCoeff[idx] - base), goRice));
             if (absCoeff[idx] > (3 << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
           }
           if (absCoeff[idx] >= 2) firstCoeff2 = 0;
         }
     }
   }
+  g_S.cab[c].frac += fr; g_S.cab[c].bins += nb;
+#undef FCU_BIN
+#undef FCU_EP
 }
 
 /* ======================================================================================== */
@@ -516,6 +546,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   const Params &P = *FCU_UNI(&P_);
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp); cbfCtx = FCU_UNI(cbfCtx);
   if (SER) { c = FCU_UNI(c); src = FCU_UNI(src); dst = FCU_UNI(dst); topNZ = FCU_UNI(topNZ); scanType = FCU_UNI(scanType); rec = FCU_UNI(rec); costCGSig = FCU_UNI(costCGSig); }
+  FCU_RTIC(rt_);
   if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
   const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
   FCU_HBM RdoqRec *recg = (FCU_HBM RdoqRec *)rec; FCU_HBM double *cgg = (FCU_HBM double *)costCGSig;
@@ -548,6 +579,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
     for (int k = 15; k >= 0; k--) { const double err = (double)iabs(v[k]); blockUncodedCost += err * err * errScale; }
   }
   baseCost = blockUncodedCost;
+  FCU_RTOC(P, rt_, 11);                                       /* set-up + uncoded tail */
   int32_t ahead = srcg[(cgTop * 16 + 15) * st];
   for (int cgScanPos = cgTop; cgScanPos >= 0; cgScanPos--) {
     const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
@@ -593,9 +625,9 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           cs = lambda * (double)sbit0; cc = c0 + cs;
           RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = g10; r.dn = 0; r.sd = sbit1 - sbit0;
           r.du = (int32_t)(levelDouble >> (qbits - 8));
-          recg[scanPos * st] = r;
+          if (SER) g_S.rq_rec[posInCG] = r; else recg[scanPos * st] = r;
           baseCost += cc;
-          dstg[scanPos * st] = 0;
+          if (SER) g_S.rq_lv[posInCG] = 0; else dstg[scanPos * st] = 0;
           rdSigCost += cs;
           if (posInCG == 0) rdSigCost0 = cs;
           continue;
@@ -618,7 +650,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         }
         RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = rup; r.dn = rdn; r.sd = sdel;
         r.du = (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8));
-        recg[scanPos * st] = r;
+        if (SER) g_S.rq_rec[posInCG] = r; else recg[scanPos * st] = r;
         baseCost += cc;
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
@@ -626,7 +658,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
       } else baseCost += c0;
-      dstg[scanPos * st] = (int16_t)level;
+      if (SER) g_S.rq_lv[posInCG] = (int16_t)level; else dstg[scanPos * st] = (int16_t)level;
       rdSigCost += cs;
       if (posInCG == 0) rdSigCost0 = cs;
       if (level) {
@@ -659,13 +691,19 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
             cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
             for (int posInCG = 15; posInCG >= 0; posInCG--) {
               const int scanPos = cgScanPos * 16 + posInCG;
-              if (dstg[scanPos * st]) { dstg[scanPos * st] = 0; recg[scanPos * st].cc = recg[scanPos * st].c0; recg[scanPos * st].cs = 0; }
+              if (SER) { if (g_S.rq_lv[posInCG]) { g_S.rq_lv[posInCG] = 0; g_S.rq_rec[posInCG].cc = g_S.rq_rec[posInCG].c0; g_S.rq_rec[posInCG].cs = 0; } }
+              else if (dstg[scanPos * st]) { dstg[scanPos * st] = 0; recg[scanPos * st].cc = recg[scanPos * st].c0; recg[scanPos * st].cs = 0; }
             }
           }
         }
       } else cgflag |= 1ull << cgBlk;
     }
+    if (SER) {                                               /* the serial variant kept the group in LDS: one burst of stores per group */
+#pragma unroll
+      for (int k = 0; k < 16; k++) { recg[(cgScanPos * 16 + k) * st] = g_S.rq_rec[k]; dstg[(cgScanPos * 16 + k) * st] = g_S.rq_lv[k]; }
+    }
   }
+  FCU_RTOC(P, rt_, 12);                                       /* main loop */
   if (lastScanPos < 0) { RdoqOut z = { 0, -1 }; return z; }
 
   double bestCost; int bestLastIdxP1 = 0;
@@ -708,17 +746,17 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
       if (foundLast) break;
     }
   }
-  {
-    int aL = bestLastIdxP1 > 0 ? dstg[0] : 0; int32_t aS = bestLastIdxP1 > 0 ? srcg[0] : 0;           /* one ahead */
-    for (int sp = 0; sp < bestLastIdxP1; sp++) {
-      const int level = aL; const int32_t sv = aS;
-      if (sp + 1 < bestLastIdxP1) { aL = dstg[(sp + 1) * st]; aS = srcg[(sp + 1) * st]; }
-      absSum += level;
-      dstg[sp * st] = (int16_t)((sv < 0) ? -level : level);
-    }
+  FCU_RTOC(P, rt_, 13);                                       /* last-position search */
+  for (int sp0 = 0; sp0 < bestLastIdxP1; sp0 += 16) {           /* signs back on the kept levels, sixteen positions per round of loads */
+    int lv[16]; int32_t sv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int ok = sp0 + k < bestLastIdxP1; lv[k] = ok ? dstg[(sp0 + k) * st] : 0; sv[k] = ok ? srcg[(sp0 + k) * st] : 0; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (sp0 + k < bestLastIdxP1) { absSum += lv[k]; dstg[(sp0 + k) * st] = (int16_t)((sv[k] < 0) ? -lv[k] : lv[k]); }
   }
   for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
 
+  FCU_RTOC(P, rt_, 14);                                       /* signs */
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
@@ -763,6 +801,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
       if (lastCG == 1) lastCG = 0;
     }
   }
+  FCU_RTOC(P, rt_, 15);                                       /* sign hiding */
   int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
   while (last >= 0 && dstg[last * st] == 0) last--;
   RdoqOut o = { absSum, last };
