@@ -143,7 +143,7 @@ struct Chain {
   fcu_ctu_out *out;
   Params p;
   int w_ctu, h_ctu, n_ctu;
-  int next_ctu;
+  int next_ctu, end_ctu;       /* the chain decides CTUs [next_ctu, end_ctu): the whole frame, or whole slices of it */
   Cabac state;                 /* m_pppcRDSbacCoder[0][CI_CURR_BEST] between CTUs */
   unsigned long long n_tu_trials;
   unsigned long long prof[16];

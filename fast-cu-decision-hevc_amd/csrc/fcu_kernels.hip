@@ -25,7 +25,7 @@ __device__ __noinline__ static void run_chain(Chain *C, Scratch *G, int ctus)
   load_hot_tables();
   for (int k = 0; k < ctus; k++) {
     const int a = C->next_ctu;
-    if (a >= C->n_ctu || C->out == nullptr) break;          /* every wave reaches this exit */
+    if (a >= C->end_ctu || C->out == nullptr) break;        /* every wave reaches this exit */
     compress_ctu(C, G, a);
     FCU_SERIAL { C->next_ctu = a + 1; }
   }
@@ -102,8 +102,25 @@ int fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
   h.stride[0] = c->sp.width; h.stride[1] = h.stride[2] = c->sp.width / 2;
   h.out = dev_out;
   h.w_ctu = (c->sp.width + 63) / 64; h.h_ctu = (c->sp.height + 63) / 64; h.n_ctu = h.w_ctu * h.h_ctu;
-  h.next_ctu = 0;
+  h.next_ctu = 0; h.end_ctu = h.n_ctu;
   c->h_pos[(size_t)chain] = 0;
+  HIPCHK(hipMemcpy(&c->d_chains[chain], &h, sizeof(Chain), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+int fcu_chain_set_range(fcu_ctx *c, int chain, int first_ctu, int n_ctus)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_chain_set_range: bad argument");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_range: chain not bound (fcu_chain_begin)");
+  const int sl = h.p.slice_ctus;
+  if (first_ctu < 0 || n_ctus <= 0 || first_ctu + n_ctus > h.n_ctu) return fail(FCU_ERR_ARG, "fcu_chain_set_range: range outside the frame");
+  /* a chain may only start where the reference resets its entropy coder and cuts the neighbourhood: at a slice start */
+  if (first_ctu != 0 && (sl <= 0 || first_ctu % sl != 0)) return fail(FCU_ERR_ARG, "fcu_chain_set_range: a chain must start at a slice boundary");
+  if (first_ctu + n_ctus != h.n_ctu && (sl <= 0 || (first_ctu + n_ctus) % sl != 0)) return fail(FCU_ERR_ARG, "fcu_chain_set_range: a chain must end at a slice boundary");
+  HIPCHK(hipSetDevice(c->sp.device));
+  h.next_ctu = first_ctu; h.end_ctu = first_ctu + n_ctus;
+  c->h_pos[(size_t)chain] = first_ctu;
   HIPCHK(hipMemcpy(&c->d_chains[chain], &h, sizeof(Chain), hipMemcpyHostToDevice));
   return FCU_OK;
 }
@@ -121,7 +138,7 @@ int fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, st));
   c->ev.push_back(e0); c->ev.push_back(e1);
-  for (int i = first; i < first + n; i++) { int &p = c->h_pos[(size_t)i]; p += ctus; if (p > c->n_ctu) p = c->n_ctu; }
+  for (int i = first; i < first + n; i++) { int &p = c->h_pos[(size_t)i]; p += ctus; if (p > c->h_chains[(size_t)i].end_ctu) p = c->h_chains[(size_t)i].end_ctu; }
   return FCU_OK;
 }
 
@@ -159,7 +176,7 @@ int fcu_chain_position(fcu_ctx *c, int chain)
 int fcu_compress_ctu(fcu_ctx *c, int chain, uint32_t ctuRsAddr, fcu_ctu_out *host_out)
 {
   if (!c || chain < 0 || chain >= c->sp.max_chains || !host_out) return fail(FCU_ERR_ARG, "fcu_compress_ctu: bad argument");
-  if ((int)ctuRsAddr != c->h_pos[(size_t)chain] || (int)ctuRsAddr >= c->n_ctu) return fail(FCU_ERR_STATE, "fcu_compress_ctu: CTUs of a chain must be decided in raster order");
+  if ((int)ctuRsAddr != c->h_pos[(size_t)chain] || (int)ctuRsAddr >= c->h_chains[(size_t)chain].end_ctu) return fail(FCU_ERR_STATE, "fcu_compress_ctu: CTUs of a chain must be decided in raster order");
   int r = fcu_compress_chains(c, chain, 1, 1, nullptr);
   if (r != FCU_OK) return r;
   HIPCHK(hipDeviceSynchronize());

@@ -49,7 +49,7 @@ CTU_OUT_BYTES = C.sizeof(CtuOut)
 
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
-           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters"]
+           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range"]
 
 
 def lib_path():
@@ -75,6 +75,7 @@ def load_lib():
     lib.fcu_default_frame_params.argtypes = [C.POINTER(FrameParams), C.c_int]
     lib.fcu_chain_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameParams)] + [C.c_void_p] * 7
     lib.fcu_compress_chains.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.fcu_chain_set_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fcu_compress_ctu.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(CtuOut)]
     lib.fcu_get_ctx_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fcu_chain_position.argtypes = [C.c_void_p, C.c_int]
@@ -150,6 +151,22 @@ class CuEngine:
                                            *[p.data_ptr() for p in rec], out.data_ptr()), "fcu_chain_begin")
         self._keep[chain] = (planes, rec, out)
         return rec, out
+
+    def init_slice_chains(self, first_chain, org, qp, slice_ctus, **flags):
+        """One frame as ceil(n_ctu / slice_ctus) chains, one per slice (SliceMode 1): they share the frame's
+        source / reconstruction planes and fcu_ctu_out array.  Returns (n_slices, rec, out)."""
+        n_sl = (self.n_ctu + slice_ctus - 1) // slice_ctus
+        rec, out = self.init_chain(first_chain, org, qp, slice_ctus=slice_ctus, **flags)
+        planes = self._keep[first_chain][0]
+        for k in range(n_sl):
+            if k:
+                self.init_chain(first_chain + k, planes, qp, slice_ctus=slice_ctus, rec=rec, out=out, **flags)
+            first = k * slice_ctus
+            self.set_range(first_chain + k, first, min(slice_ctus, self.n_ctu - first))
+        return n_sl, rec, out
+
+    def set_range(self, chain, first_ctu, n_ctus):
+        self._chk(self.lib.fcu_chain_set_range(self.h, chain, first_ctu, n_ctus), "fcu_chain_set_range")
 
     # -- TEncCu::compressCtu (+ encodeCtu replay)
     def compress_ctu(self, chain, ctu_rs_addr):

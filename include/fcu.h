@@ -9,6 +9,8 @@
  *   TEncCu::destroy (TEncCu.cpp:214)              fcu_destroy
  *   TEncCu::init + TEncSlice::setUpLambda         fcu_chain_begin   (per slice-chain parameters,
  *     (TEncCu.cpp:306, TEncSlice.cpp:496-524)                        lambda as f64 bit patterns)
+ *   slice loop of TEncGOP::compressGOP             fcu_chain_set_range (one chain per slice of a frame)
+ *     (TEncGOP.cpp:1102-1138, SliceMode 1)
  *   TEncCu::compressCtu (TEncCu.cpp:329)          fcu_compress_ctu  (one CTU of one chain) /
  *     + TEncCu::encodeCtu context replay          fcu_compress_chains (batched, many chains)
  *     (TEncCu.cpp:359, TEncSlice.cpp:1468-1487)
@@ -76,6 +78,11 @@ int  fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
                      const uint8_t *dev_org_y, const uint8_t *dev_org_u, const uint8_t *dev_org_v,
                      uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
                      fcu_ctu_out *dev_out);
+/* Restrict a bound chain to the CTUs [first_ctu, first_ctu + n_ctus) of its frame.  Both ends must be slice
+ * boundaries (frame_params.slice_ctus), where HM resets the entropy coder (TEncSlice.cpp:1392-1395) and masks the
+ * neighbourhood (TComDataCU::getPULeft/Above): the slices of ONE frame then run as independent chains that share
+ * the frame's planes and fcu_ctu_out array (disjoint writes) -- the way a single frame is spread over chains / GPUs. */
+int  fcu_chain_set_range(fcu_ctx *c, int chain, int first_ctu, int n_ctus);
 /* Advance chains [first, first+n) by up to `ctus` CTUs each (raster order; compressCtu +
  * encodeCtu replay per CTU).  Asynchronous on `hip_stream` (hipStream_t or NULL). */
 int  fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream);

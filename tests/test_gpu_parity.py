@@ -78,3 +78,46 @@ def test_raster_order_is_enforced(pkg):
     with pytest.raises(pkg.FcuError):
         eng.compress_ctu(0, 1)                # CTU 0 has not been decided yet
     eng.destroy()
+
+
+def test_full_4k_frame_as_slice_chains(pkg):
+    """BASELINE configs[2] size: one 3840x2160 frame, SliceMode 1 with one CTU row (60 CTUs) per slice, decided as 34
+    independent chains in one launch sequence -- every one of the 2040 CTUs (partial bottom row included) bit-exact
+    against the oracle run on the same frame with the same slicing, plus the reconstruction planes."""
+    import torch
+    w, h, qp, sl = 3840, 2160, 32, 60
+    Y, U, V = pkg.synth.textured(w, h, seed=7)
+    eng = pkg.CuEngine(w, h, max_chains=34)
+    n_sl, rec, out = eng.init_slice_chains(0, (Y, U, V), qp, sl)
+    assert n_sl == 34 and eng.n_ctu == 2040
+    eng.compress_chains(0, n_sl, sl)
+    eng.sync()
+    assert [eng.position(k) for k in range(n_sl)] == [min((k + 1) * sl, eng.n_ctu) for k in range(n_sl)]
+    ref = hmo_py.Encoder(Y, U, V, qp, slice_ctus=sl)
+    ref.compress_frame()
+    raw = out.cpu().numpy()
+    nbytes = pkg.engine.CTU_OUT_BYTES
+    for a in range(eng.n_ctu):
+        got = pkg.engine.ctu_to_dict(pkg.engine.CtuOut.from_buffer_copy(raw[a * nbytes:(a + 1) * nbytes].tobytes()))
+        _compare_ctu(got, ref.ctu_arrays(a), f"4K ctu{a}")
+    for p, q in zip([t.cpu().numpy() for t in rec], ref.rec):
+        assert np.array_equal(p, q)
+    # the chain of the last slice ends in the same coder state as the oracle (which ran the slices in order)
+    ctx_e, frac_e = eng.ctx_state(n_sl - 1)
+    ctx_o, frac_o = ref.cabac()
+    assert np.array_equal(ctx_e, ctx_o) and frac_e == frac_o
+    eng.destroy()
+
+
+def test_chain_range_must_follow_slices(pkg):
+    w, h = 256, 128
+    Y, U, V = pkg.synth.mixed(w, h, seed=3)
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    eng.init_chain(0, (Y, U, V), qp=32, slice_ctus=4)
+    with pytest.raises(pkg.FcuError):
+        eng.set_range(0, 2, 4)          # does not start at a slice boundary
+    with pytest.raises(pkg.FcuError):
+        eng.set_range(0, 4, 3)          # does not end at one
+    eng.set_range(0, 4, 4)
+    assert eng.position(0) == 4
+    eng.destroy()
