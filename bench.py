@@ -24,6 +24,21 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 1024 + rec 12288 + coeff 24576 + meta 5120
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+
+
+def measured_traffic(chains, ctus_per_step):
+    """HBM-side bytes per launch of the engine kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the summary is for another workload shape."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+        if d.get("chains_per_launch") != chains or d.get("ctus_per_chain_per_launch") != ctus_per_step:
+            return None
+        return float(d["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def gen_textured_gpu(torch, dev, w, h, seed):
@@ -140,7 +155,7 @@ def main():
                                    f"{args.ctus_per_step} CTU/chain/step",
                        "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(n_chains, args.ctus_per_step),
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches},
         }
         if not args.no_cpu_baseline:

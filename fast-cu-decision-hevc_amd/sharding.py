@@ -8,6 +8,18 @@ def chains_for_rank(frames_per_gpu, qps, rank):
     return [(7 + f + 1000 * rank, qp) for f in range(frames_per_gpu) for qp in qps]
 
 
+def slices_for_rank(n_ctu, slice_ctus, world, rank):
+    """One frame over several GPUs: contiguous runs of whole slices per rank, as
+    [(first_ctu, n_ctus)] chain ranges for fcu_chain_set_range.  No rank shares a slice."""
+    n_sl = (n_ctu + slice_ctus - 1) // slice_ctus
+    per = (n_sl + world - 1) // world
+    out = []
+    for k in range(rank * per, min(n_sl, (rank + 1) * per)):
+        first = k * slice_ctus
+        out.append((first, min(slice_ctus, n_ctu - first)))
+    return out
+
+
 def reduce_step_time(dist, local_seconds, device=None):
     """Slowest rank defines the step time (MAX all-reduce); returns local_seconds when single-process."""
     if dist is None:

@@ -52,3 +52,14 @@ def test_bad_arguments_are_rejected(built, pkg):
     sp = pkg.engine.SeqParams(130, 64, 1, 0)            # width not a multiple of the minimum CU size
     assert lib.fcu_create(C.byref(sp), C.byref(h)) == -2
     assert lib.fcu_chain_position(None, 0) == -1
+
+
+def test_slices_partition_a_frame(pkg):
+    """4K frame, one CTU row per slice, 8 ranks: every CTU belongs to exactly one chain range."""
+    n_ctu, sl = 2040, 60
+    seen = []
+    for rank in range(8):
+        for first, n in pkg.sharding.slices_for_rank(n_ctu, sl, 8, rank):
+            assert first % sl == 0 and n > 0
+            seen += list(range(first, first + n))
+    assert seen == list(range(n_ctu))
