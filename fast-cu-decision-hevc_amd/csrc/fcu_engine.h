@@ -121,7 +121,7 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
        CTX_TSKIP = 157, NCTX = 160 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
-enum { MAXVC = 20, POOL = 5120, DIFFN = 512 };   /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
+enum { MAXVC = 20, POOL = 5120 };   /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
 #define FCU_MAX_DOUBLE 1.7e+308
 
 /* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
@@ -191,11 +191,10 @@ struct Shared {
   uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
   union {                                           /* never live at the same time */
     int16_t lane_abs[MAXVC][16];                    /* per-lane |level| list of the coefficient group being coded */
-    int32_t colsum[128];                            /* SATD column sums / availability flags of build_ref */
+    int32_t colsum[128];                            /* availability flags of build_ref / chroma_leaf_refs5 */
     RdoqRec rq_rec[16];                             /* serial RDOQ: records of the coefficient group in flight */
   };
   int16_t rq_lv[16];                                /* serial RDOQ: levels of the coefficient group in flight */
-  int16_t diff[DIFFN];
   uint32_t sad[36];
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
@@ -1527,6 +1526,40 @@ FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(Env E, CuObj *cu, TU root, Yu
 /* RMD: 35 predictions + Hadamard SATD staged through LDS (TEncSearch.cpp:2300-2361,          */
 /* TComRdCost.cpp:1343-1604) and the sorted candidate list (xUpdateCandList :5345-5370)       */
 /* ======================================================================================== */
+/* SATD of one USZ x USZ block of (source - prediction) for one mode (xCalcHADs8x8 / xCalcHADs4x4, TComRdCost.cpp:1343-1534).
+ * Row by row: predict, row butterfly, then add the row into the USZ*USZ column-transform accumulators with the sign of the
+ * Sylvester matrix (-1)^popcount(k & y); the sum of magnitudes does not depend on the order of the Hadamard outputs. */
+template <int USZ>
+FCU_DEV uint32_t satd_unit(const uint8_t *org, int log2, int mode, int dc, int bx, int by)
+{
+  const uint8_t *r = use_filtered_ref(mode, log2, 1) ? g_S.reff : g_S.ref;
+  int acc[USZ * USZ];
+#pragma unroll
+  for (int i = 0; i < USZ * USZ; i++) acc[i] = 0;
+  for (int y = 0; y < USZ; y++) {
+    uint8_t o[USZ]; int row[USZ];
+    __builtin_memcpy(o, org + (by + y) * 64 + bx, USZ);
+#pragma unroll
+    for (int x = 0; x < USZ; x++) row[x] = (int)o[x] - pred_pixel(r, log2, mode, 1, dc, bx + x, by + y);
+#pragma unroll
+    for (int len = 1; len < USZ; len <<= 1)
+#pragma unroll
+      for (int i = 0; i < USZ; i += 2 * len)
+#pragma unroll
+        for (int j = i; j < i + len; j++) { const int a = row[j], b = row[j + len]; row[j] = a + b; row[j + len] = a - b; }
+#pragma unroll
+    for (int k = 0; k < USZ; k++) {
+      const int neg = -(__builtin_popcount((unsigned)(k & y)) & 1);          /* 0 or -1 */
+#pragma unroll
+      for (int j = 0; j < USZ; j++) acc[k * USZ + j] += (row[j] ^ neg) - neg;
+    }
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < USZ * USZ; i++) s += iabs(acc[i]);
+  return (uint32_t)(USZ == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
+}
+
 FCU_DEV FCU_NOINLINE void rmd(Env E, CuObj *cu, TU tu)
 {
   E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
@@ -1534,43 +1567,15 @@ FCU_DEV FCU_NOINLINE void rmd(Env E, CuObj *cu, TU tu)
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
   build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
-  const int usz = N >= 8 ? 8 : 4, ul = usz == 8 ? 3 : 2, upix = usz * usz, bpr = N / usz, nblk = bpr * bpr;
-  const int totalUnits = 35 * nblk, K = (DIFFN / upix) < (128 / usz) ? (DIFFN / upix) : (128 / usz);
+  /* one (mode, Hadamard block) unit per lane, entirely in registers: no staging, no barrier between the stages */
   FCU_FOR_LANES { if (lane < 36) g_S.sad[lane] = 0; }
-  for (int u0 = 0; u0 < totalUnits; u0 += K) {
-    const int nu = (totalUnits - u0) < K ? (totalUnits - u0) : K;
-    FCU_FOR_LANES {                                          /* residual of unit u = (mode, block) */
-      const int dc = g_S.dc;
-      for (int i = lane; i < nu * upix; i += 64) {
-        const int u = u0 + (i >> (2 * ul)), p = i & (upix - 1), mode = u / nblk, blk = u % nblk;
-        const int x = (blk % bpr) * usz + (p & (usz - 1)), y = (blk / bpr) * usz + (p >> ul);
-        const uint8_t *r = use_filtered_ref(mode, log2, 1) ? g_S.reff : g_S.ref;
-        g_S.diff[i] = (int16_t)(org[y * 64 + x] - pred_pixel(r, log2, mode, 1, dc, x, y));
-      }
-    }
-    FCU_FOR_LANES {                                          /* rows */
-      for (int it = lane; it < nu * usz; it += 64) {
-        int16_t *row = g_S.diff + it * usz; int v[8];
-        for (int k = 0; k < usz; k++) v[k] = row[k];
-        for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
-        for (int k = 0; k < usz; k++) row[k] = (int16_t)v[k];
-      }
-    }
-    FCU_FOR_LANES {                                          /* columns + abs sum */
-      for (int it = lane; it < nu * usz; it += 64) {
-        const int16_t *col = g_S.diff + (it >> ul) * upix + (it & (usz - 1)); int v[8];
-        for (int k = 0; k < usz; k++) v[k] = col[k * usz];
-        for (int len = 1; len < usz; len <<= 1) for (int i = 0; i < usz; i += 2 * len) for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
-        int s = 0; for (int k = 0; k < usz; k++) s += iabs(v[k]);
-        g_S.colsum[it] = s;
-      }
-    }
-    FCU_FOR_LANES {
-      for (int uu = lane; uu < nu; uu += 64) {
-        int s = 0; for (int k = 0; k < usz; k++) s += g_S.colsum[uu * usz + k];
-        const uint32_t v = (uint32_t)(usz == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
-        FCU_ATOMIC_ADD(&g_S.sad[(u0 + uu) / nblk], v);
-      }
+  FCU_FOR_LANES {
+    const int dc = g_S.dc;
+    if (N >= 8) {
+      const int bpr = N >> 3, nblk = bpr * bpr;
+      for (int u = lane; u < 35 * nblk; u += 64) { const int mode = u / nblk, blk = u - mode * nblk; FCU_ATOMIC_ADD(&g_S.sad[mode], satd_unit<8>(org, log2, mode, dc, (blk % bpr) * 8, (blk / bpr) * 8)); }
+    } else {
+      for (int u = lane; u < 35; u += 64) FCU_ATOMIC_ADD(&g_S.sad[u], satd_unit<4>(org, log2, u, dc, 0, 0));
     }
   }
   /* mode bits + sorted insert (serial) */
