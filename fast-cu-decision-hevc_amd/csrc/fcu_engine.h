@@ -834,7 +834,11 @@ FCU_DEV int pred_pixel(const uint8_t *ref, int log2, int mode, int isLuma, int d
   }
   const int isVer = mode >= 18;
   const int angMode = isVer ? mode - VER : -(mode - HOR);
-  const int absAng = iabs(angMode), angle = (angMode < 0 ? -1 : 1) * k_ang[absAng], invAngle = k_inv_ang[absAng];
+  /* intraPredAngle / invAngle (TComPrediction.cpp:287-288) packed into constants: 9 x 6 bits, 8 x 13 bits (no table loads per pixel) */
+  const int absAng = iabs(angMode);
+  const int angAbs = (int)((0x2069544d245080ull >> (6 * absAng)) & 63);
+  const int invAngle = absAng == 0 ? 0 : (int)(((absAng <= 4 ? 0x13b0e38ccd000ull : 0x8004ec30c1e2ull) >> (13 * ((absAng - 1) & 3))) & 8191);
+  const int angle = angMode < 0 ? -angAbs : angAbs;
   const int px = isVer ? x : y, py = isVer ? y : x, ms = isVer ? 1 : -1;   /* main array direction from the corner */
   if (angle == 0) {
     int v = corner[ms * (px + 1)];
@@ -959,13 +963,21 @@ template <int LOG2> FCU_DEV int32_t inv1(const int32_t *deqT, int useDst, int id
 { constexpr int N = 1 << LOG2; const int y = idx >> LOG2, kh = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, y), deqT + (kh << LOG2)) + 64) >> 7); }
 template <int LOG2> FCU_DEV int32_t inv2(const int32_t *tmp2, int useDst, int idx)
 { constexpr int N = 1 << LOG2; const int y = idx >> LOG2, x = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, x), tmp2 + (y << LOG2)) + 2048) >> 12); }
-FCU_DEV int32_t dequant1(int q, int log2, int qp)          /* xDeQuant flat, TComTrQuant.cpp:1242-1352 */
+struct DeqParams { int scale, rs, lo, hi; };                /* xDeQuant flat, TComTrQuant.cpp:1242-1352: loop invariants of one TU */
+FCU_DEV DeqParams deq_params(int log2, int qp)
 {
-  const int per = qp / 6, rem = qp % 6, rs = 6 - ((15 - 8 - log2) + per), scale = k_inv_quant_scales[rem];
-  int tbd = 32 + rs - 7; if (tbd > 16) tbd = 16;
-  const int c = clip3i(-(1 << (tbd - 1)), (1 << (tbd - 1)) - 1, q);
-  if (rs > 0) return clip3i(-32768, 32767, (c * scale + (1 << (rs - 1))) >> rs);
-  return clip3i(-32768, 32767, (c * scale) << (-rs));
+  DeqParams d;
+  const int per = qp / 6, rem = qp % 6;
+  d.rs = 6 - ((15 - 8 - log2) + per); d.scale = k_inv_quant_scales[rem];
+  int tbd = 32 + d.rs - 7; if (tbd > 16) tbd = 16;
+  d.lo = -(1 << (tbd - 1)); d.hi = (1 << (tbd - 1)) - 1;
+  return d;
+}
+FCU_DEV int32_t dequant1(int q, const DeqParams &d)
+{
+  const int c = clip3i(d.lo, d.hi, q);
+  if (d.rs > 0) return clip3i(-32768, 32767, (c * d.scale + (1 << (d.rs - 1))) >> d.rs);
+  return clip3i(-32768, 32767, (c * d.scale) << (-d.rs));
 }
 
 /* ======================================================================================== */
@@ -1345,7 +1357,8 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
     const int np = comp ? tu_nparts_c(tu) : tu.nparts;
     for (int i = lane; i < np; i += 64) cu->cbf[comp][part + i] = (uint8_t)((absSum > 0 ? 1 : 0) << tu.tr_depth);
     const int cgEnd = ((g_S.t_last >> 4) + 1) << 4;                /* RDOQ wrote the levels of scan positions < cgEnd */
-    for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int q = (absSum > 0 && sp < cgEnd) ? G->p_qscan[sp] : 0; coef[sp] = (int16_t)q; G->p_tmp[useTS ? i : tr_index(i, log2)] = dequant1(q, log2, qp); }
+    const DeqParams dq = deq_params(log2, qp);
+    for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int q = (absSum > 0 && sp < cgEnd) ? G->p_qscan[sp] : 0; coef[sp] = (int16_t)q; G->p_tmp[useTS ? i : tr_index(i, log2)] = dequant1(q, dq); }
   }
   if (absSum > 0) {
     if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
@@ -1666,12 +1679,13 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
   }
   FCU_TOC(E, t2_, 2);
   FCU_FOR_LANES {                                            /* levels back to raster order + dequantisation */
+    const DeqParams dq = deq_params(log2, P.qp);
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2;
       const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v / tsv], log2, 0) * 4 + log2 - 2];
       const int sp = iscan[p];
       const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-      G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, log2, P.qp);
+      G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
     }
   }
   FCU_FOR_LANES {
@@ -1965,13 +1979,14 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
             }
             FCU_TOC(E, t13_, 13);
             FCU_FOR_LANES {                                      /* levels back to raster order + dequantisation */
+              const DeqParams dq = deq_params(log2, P.qp_c);
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
                 const int sp = iscan[p];
                 const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-                G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, log2, P.qp_c);
+                G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
               }
             }
             FCU_FOR_LANES {
