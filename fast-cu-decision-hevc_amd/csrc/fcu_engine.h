@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #define FCU_DEV static inline
 #define FCU_NOINLINE
+#define FCU_INLINE
 #define FCU_TABLE static const
 #define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
@@ -44,6 +45,7 @@
 #else
 #define FCU_DEV __device__ static
 #define FCU_NOINLINE __noinline__
+#define FCU_INLINE __attribute__((always_inline))
 #define FCU_TABLE __device__ static const
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
@@ -356,7 +358,7 @@ FCU_DEV int coef_remain_bins(uint32_t symbol, uint32_t rparam)             /* by
  * derived group by group on the way down (a group's right/below neighbours come earlier in reverse scan). */
 /* SER = 1: called by one lane (serial sections): every argument is wave-uniform */
 template <int SER>
-FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int last, int log2, int comp, int scanType, int tsFlag, const Params &P_, int16_t *absCoeff)
+FCU_DEV FCU_INLINE void code_coeff_body(int c, const int16_t *coef, int st, int last, int log2, int comp, int scanType, int tsFlag, const Params &P_, int16_t *absCoeff)
 {
   if (SER) { c = FCU_UNI(c); coef = FCU_UNI(coef); last = FCU_UNI(last); scanType = FCU_UNI(scanType); tsFlag = FCU_UNI(tsFlag); absCoeff = FCU_UNI(absCoeff); }
   const Params &P = *FCU_UNI(&P_);
@@ -471,6 +473,10 @@ FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int
 #undef FCU_BIN
 #undef FCU_EP
 }
+
+template <int SER>
+FCU_DEV FCU_NOINLINE void code_coeff_nxn(int c, const int16_t *coef, int st, int last, int log2, int comp, int scanType, int tsFlag, const Params &P, int16_t *absCoeff)
+{ code_coeff_body<SER>(c, coef, st, last, log2, comp, scanType, tsFlag, P, absCoeff); }
 
 /* ======================================================================================== */
 /* RDOQ -- per-lane callable (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:2033-2573)     */
@@ -1142,7 +1148,7 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(Env E, int c, const CuObj *cu, TU t
     cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
   const int cbf = g_S.t_abs > 0;
   cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-  if (cbf) code_coeff_nxn<1>(c, E.G->p_qscan, 1, g_S.t_lsp, log2, 0, coef_scan_idx(cu->intra_dir[0][part], log2, 0), cu->tskip[0][part], E.C->p, g_S.lane_abs[0]);
+  if (cbf) code_coeff_body<1>(c, E.G->p_qscan, 1, g_S.t_lsp, log2, 0, coef_scan_idx(cu->intra_dir[0][part], log2, 0), cu->tskip[0][part], E.C->p, g_S.lane_abs[0]);
   return cab_bits(c);
 }
 
