@@ -14,12 +14,14 @@ using namespace fcu;
 struct EmuChain { Chain c; Scratch *g; };
 
 extern "C" {
-void *fcu_emu_create(int width, int height, int qp, int slice_ctus, const uint8_t *oy, const uint8_t *ou, const uint8_t *ov,
+/* tools: bit 0 transform_skip, 1 transform_skip_fast, 2 sign_hiding, 3 strong_intra_smoothing; -1 = defaults */
+void *fcu_emu_create(int width, int height, int qp, int slice_ctus, int tools, const uint8_t *oy, const uint8_t *ou, const uint8_t *ov,
                      uint8_t *ry, uint8_t *ru, uint8_t *rv, fcu_ctu_out *out)
 {
   EmuChain *e = new EmuChain();
   memset(&e->c, 0, sizeof(e->c));
   fcu_frame_params fp; default_frame_params(fp, qp); fp.slice_ctus = slice_ctus;
+  if (tools >= 0) { fp.transform_skip = tools & 1; fp.transform_skip_fast = (tools >> 1) & 1; fp.sign_hiding = (tools >> 2) & 1; fp.strong_intra_smoothing = (tools >> 3) & 1; }
   fill_params(e->c.p, width, height, fp);
   e->c.org[0] = oy; e->c.org[1] = ou; e->c.org[2] = ov; e->c.rec[0] = ry; e->c.rec[1] = ru; e->c.rec[2] = rv;
   e->c.stride[0] = width; e->c.stride[1] = e->c.stride[2] = width / 2;

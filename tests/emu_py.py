@@ -12,7 +12,7 @@ from hmo_py import Ctu  # same TComDataCU layout as include/fcu.h:fcu_ctu_out
 def load():
     lib = C.CDLL(os.path.join(_HERE, "emu", "libfcu_emu.so"))
     lib.fcu_emu_create.restype = C.c_void_p
-    lib.fcu_emu_create.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7
+    lib.fcu_emu_create.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
     lib.fcu_emu_destroy.argtypes = [C.c_void_p]
     lib.fcu_emu_compress_ctu.argtypes = [C.c_void_p, C.c_int]
     lib.fcu_emu_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -22,14 +22,14 @@ def load():
 
 
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1):
         self.lib = load()
         h, w = Y.shape
         self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
         self.rec = [np.zeros_like(a) for a in self.org]
         self.n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
         self.out = (Ctu * self.n_ctu)()
-        self.h = self.lib.fcu_emu_create(w, h, qp, slice_ctus, *[a.ctypes.data for a in self.org],
+        self.h = self.lib.fcu_emu_create(w, h, qp, slice_ctus, tools, *[a.ctypes.data for a in self.org],
                                          *[a.ctypes.data for a in self.rec], C.addressof(self.out))
 
     def compress_ctu(self, a):

@@ -36,6 +36,38 @@ def test_emulated_engine_is_bit_exact(built, pkg, gen, w, h, qp, sl):
         assert np.array_equal(p, q)
 
 
+TOOLSETS = [
+    # (transform_skip, transform_skip_fast, sign_hiding, strong_intra_smoothing)
+    (0, 0, 1, 1),       # no transform skip
+    (1, 0, 1, 1),       # transform skip tried for every 4x4 TU (TransformSkipFast 0)
+    (1, 1, 0, 1),       # no sign-bit hiding
+    (1, 1, 1, 0),       # no strong intra smoothing
+]
+
+
+@pytest.mark.parametrize("ts,tsf,sbh,strong", TOOLSETS)
+def test_tool_flags(built, pkg, ts, tsf, sbh, strong):
+    """The PPS/SPS tool switches of the boundary (fcu_frame_params) against the oracle run with the same switches."""
+    import emu_py
+    Y, U, V = pkg.synth.mixed(128, 64, seed=9)
+    o = hmo_py.Encoder(Y, U, V, 27, transform_skip=ts, transform_skip_fast=tsf, sign_hiding=sbh, strong_smoothing=strong)
+    e = emu_py.EmuEncoder(Y, U, V, 27, tools=ts | (tsf << 1) | (sbh << 2) | (strong << 3))
+    for a in range(o.n_ctu):
+        o.compress_ctu(a)
+        e.compress_ctu(a)
+        A, B = o.ctu_arrays(a), e.ctu_arrays(a)
+        for k, v in A.items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(v, B[k]), (a, k)
+            else:
+                assert v == B[k], (a, k, v, B[k])
+        ca, fa = o.cabac()
+        cb, fb = e.cabac()
+        assert np.array_equal(ca, cb) and fa == fb
+    for p, q in zip(o.rec, e.rec):
+        assert np.array_equal(p, q)
+
+
 def test_decisions_are_decodable(built, pkg):
     """Decoder-side consistency of the oracle output: re-deriving the reconstruction from the published
     modes + coefficients (prediction from already rebuilt neighbours, dequant, inverse transform) must give

@@ -121,3 +121,21 @@ def test_chain_range_must_follow_slices(pkg):
     eng.set_range(0, 4, 4)
     assert eng.position(0) == 4
     eng.destroy()
+
+
+@pytest.mark.parametrize("ts,tsf,sbh,strong", [(0, 0, 1, 1), (1, 0, 0, 0)])
+def test_tool_flags_through_the_abi(pkg, ts, tsf, sbh, strong):
+    """fcu_frame_params tool switches (TransformSkip / TransformSkipFast / SignHideFlag / StrongIntraSmoothing)."""
+    w, h, qp = 128, 64, 27
+    Y, U, V = pkg.synth.mixed(w, h, seed=9)
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    eng.init_chain(0, (Y, U, V), qp=qp, transform_skip=ts, transform_skip_fast=tsf, sign_hiding=sbh, strong_intra_smoothing=strong)
+    ref = hmo_py.Encoder(Y, U, V, qp, transform_skip=ts, transform_skip_fast=tsf, sign_hiding=sbh, strong_smoothing=strong)
+    for a in range(eng.n_ctu):
+        got = eng.compress_ctu(0, a)
+        ref.compress_ctu(a)
+        _compare_ctu(got, ref.ctu_arrays(a), f"tools {ts}{tsf}{sbh}{strong} ctu{a}")
+    ctx_e, frac_e = eng.ctx_state(0)
+    ctx_o, frac_o = ref.cabac()
+    assert np.array_equal(ctx_e, ctx_o) and frac_e == frac_o
+    eng.destroy()
