@@ -15,6 +15,7 @@
 #include <string.h>
 #include <vector>
 #include "fcu_host.h"
+#include "fcu_obf.h"
 
 using namespace fcu;
 
@@ -206,6 +207,60 @@ int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bit
   HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
   memcpy(ctx160, h.state.ctx, NCTX);
   *frac_bits = h.state.frac;
+  return FCU_OK;
+}
+
+/* ---- fork pre-pass: OBF maps of n luma planes ------------------------------------------------------------ */
+int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc, float *kernel_ms2, void *hip_stream)
+{
+  if (!c || n_frames <= 0 || !dev_y || !dev_obf) return fail(FCU_ERR_ARG, "fcu_obf_prepass: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int w = c->sp.width, h = c->sp.height, nblk = (w / 4) * (h / 4);
+  const size_t frame_bytes = (size_t)w * h, hist_n = (size_t)n_frames * 15 * OBF_HB;
+  unsigned *d_hist = nullptr; int *d_thr = nullptr;
+  HIPCHK(hipMalloc((void **)&d_hist, hist_n * sizeof(unsigned)));
+  HIPCHK(hipMalloc((void **)&d_thr, (size_t)n_frames * 16 * sizeof(int)));
+  HIPCHK(hipMemsetAsync(d_hist, 0, hist_n * sizeof(unsigned), st));
+  hipEvent_t e[4];
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&e[i]));
+  const int ngrp = (((w / 4) + 3) / 4) * (h / 4);               /* groups of four blocks along a row */
+  const dim3 grid((unsigned)((ngrp + OBF_THREADS * OBF_GROUPS_PER_THREAD - 1) / (OBF_THREADS * OBF_GROUPS_PER_THREAD)), (unsigned)n_frames);
+  HIPCHK(hipEventRecord(e[0], st));
+  hipLaunchKernelGGL(obf_hist, grid, dim3(OBF_THREADS), 0, st, dev_y, w, h, frame_bytes, d_hist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e[1], st));
+  std::vector<unsigned> hist(hist_n);
+  HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist_n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  /* threshold fit on the host (doubles + libm exp/log, as the reference), frames spread over a few threads */
+  std::vector<double> yc((size_t)n_frames * 16, 0.0);
+  std::vector<int> thr((size_t)n_frames * 16, 0);
+  {
+    const int nt = n_frames < 8 ? n_frames : 8;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++)
+      pool.emplace_back([&, t]() {
+        for (int f = t; f < n_frames; f += nt)
+          for (int x = 1; x < 16; x++) {
+            const double v = tcm_threshold(&hist[((size_t)f * 15 + (x - 1)) * OBF_HB], nblk);
+            yc[(size_t)f * 16 + x] = v; thr[(size_t)f * 16 + x] = (int)(v * 8.0);
+          }
+      });
+    for (auto &th : pool) th.join();
+  }
+  for (size_t k = 0; k < (size_t)n_frames * 15; k++)           /* the clamp bin is unreachable for 8-bit sources (|coef/8| <= 4080) */
+    if (hist[k * OBF_HB + OBF_HB - 1]) { hipFree(d_hist); hipFree(d_thr); return fail(FCU_ERR_ARG, "fcu_obf_prepass: amplitude beyond the histogram (not an 8-bit plane?)"); }
+  HIPCHK(hipMemcpyAsync(d_thr, thr.data(), thr.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(e[2], st));
+  hipLaunchKernelGGL(obf_count, grid, dim3(OBF_THREADS), 0, st, dev_y, w, h, frame_bytes, d_thr, dev_obf);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e[3], st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (kernel_ms2) { hipEventElapsedTime(&kernel_ms2[0], e[0], e[1]); hipEventElapsedTime(&kernel_ms2[1], e[2], e[3]); }
+  if (host_yc) memcpy(host_yc, yc.data(), yc.size() * sizeof(double));
+  for (int i = 0; i < 4; i++) hipEventDestroy(e[i]);
+  hipFree(d_hist); hipFree(d_thr);
   return FCU_OK;
 }
 

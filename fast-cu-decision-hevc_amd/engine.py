@@ -49,7 +49,7 @@ CTU_OUT_BYTES = C.sizeof(CtuOut)
 
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
-           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range"]
+           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass"]
 
 
 def lib_path():
@@ -76,6 +76,7 @@ def load_lib():
     lib.fcu_chain_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameParams)] + [C.c_void_p] * 7
     lib.fcu_compress_chains.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.fcu_chain_set_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.fcu_obf_prepass.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
     lib.fcu_compress_ctu.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(CtuOut)]
     lib.fcu_get_ctx_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fcu_chain_position.argtypes = [C.c_void_p, C.c_int]
@@ -206,6 +207,24 @@ class CuEngine:
     def ctu_out(self, chain, ctu_rs_addr):
         buf = self._keep[chain][2][ctu_rs_addr * CTU_OUT_BYTES:(ctu_rs_addr + 1) * CTU_OUT_BYTES].cpu().numpy()
         return ctu_to_dict(CtuOut.from_buffer_copy(buf.tobytes()))
+
+    # -- fork pre-pass (TEncSlice::getOutlierWithDCT)
+    def obf_prepass(self, luma):
+        """luma: uint8 tensor [n, height, width] on this device (or a numpy array).  Returns (obf int16 tensor
+        [n, height/4, width/4], yc float64 array [n, 16], (hist_ms, count_ms))."""
+        torch = self.torch
+        dev = torch.device("cuda", self.device)
+        t = torch.as_tensor(luma) if not torch.is_tensor(luma) else luma
+        t = t.to(device=dev, dtype=torch.uint8).contiguous()
+        if t.dim() == 2:
+            t = t[None]
+        n = t.shape[0]
+        assert tuple(t.shape[1:]) == (self.height, self.width)
+        obf = torch.zeros((n, self.height // 4, self.width // 4), dtype=torch.int16, device=dev)
+        yc = np.zeros((n, 16), np.float64)
+        ms = (C.c_float * 2)()
+        self._chk(self.lib.fcu_obf_prepass(self.h, n, t.data_ptr(), obf.data_ptr(), yc.ctypes.data, ms, None), "fcu_obf_prepass")
+        return obf, yc, (ms[0], ms[1])
 
     # -- TEncCu::destroy
     def destroy(self):

@@ -14,6 +14,8 @@
  *   TEncCu::compressCtu (TEncCu.cpp:329)          fcu_compress_ctu  (one CTU of one chain) /
  *     + TEncCu::encodeCtu context replay          fcu_compress_chains (batched, many chains)
  *     (TEncCu.cpp:359, TEncSlice.cpp:1468-1487)
+ *   TEncSlice::getOutlierWithDCT (fork pre-pass)   fcu_obf_prepass
+ *     (TEncSlice.cpp:878-1173, TEncGOP.cpp:1096)
  *   m_pppcRDSbacCoder[0][CI_CURR_BEST] state      fcu_get_ctx_state
  *     (TEncSlice.cpp:1417,1477)
  *
@@ -100,6 +102,13 @@ double fcu_kernel_ms(fcu_ctx *c, int *launches);
 /* diagnostic counters of a chain: out17[0..15] section timers (shader clocks, -DFCU_PROFILE builds only),
  * out17[16] = TU trials so far */
 int  fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17);
+/* Fork pre-pass TEncSlice::getOutlierWithDCT (TEncSlice.cpp:878-1173, called per picture at TEncGOP.cpp:1096):
+ * outlier-block-flag maps of n_frames luma planes (each width*height bytes, contiguous).  dev_obf receives
+ * n_frames * (width/4)*(height/4) int16 counts (what xCompressCU reads at TEncCu.cpp:585-603); host_yc (may be
+ * NULL) receives the 16 per-frequency TCM thresholds of every frame; kernel_ms2 (may be NULL) the durations of
+ * the histogram and the counting kernel.  Synchronous (the threshold fit runs on the host between the kernels). */
+int  fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc,
+                     float *kernel_ms2, void *hip_stream);
 const char *fcu_last_error(void);
 
 #ifdef __cplusplus

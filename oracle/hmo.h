@@ -147,6 +147,9 @@ const int16_t *hmo_dct_matrix(int log2);   /* N*N, row-major */
 const uint16_t *hmo_scan(int scanType, int log2);
 const uint8_t *hmo_zscan_to_raster(void);
 
+/* fork pre-pass (TEncSlice::getOutlierWithDCT, TEncSlice.cpp:878-1173): outlier-block-flag map of a luma plane */
+int     hmo_obf_prepass(const uint8_t *y, int w, int h, int stride, int16_t *obf, double *yc16);
+double  hmo_tcm_threshold(const int *hist, int peak, int len, int *err);
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,9 @@ def load():
     lib.hmo_get_cabac.argtypes = [C.c_void_p]
     lib.hmo_num_ctus.argtypes = [C.c_void_p]
     lib.hmo_ctu_replay_bits.restype = C.c_uint32
+    lib.hmo_obf_prepass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.hmo_tcm_threshold.restype = C.c_double
+    lib.hmo_tcm_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.hmo_ctu_replay_bits.argtypes = [C.c_void_p, C.c_int]
     return lib
 
@@ -102,3 +105,15 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+
+def obf_prepass(Y):
+    """Outlier-block-flag map of a luma plane (fork pre-pass): (obf int16 [h/4, w/4], yc float64[16])."""
+    lib = load()
+    Y = np.ascontiguousarray(Y, dtype=np.uint8)
+    h, w = Y.shape
+    obf = np.zeros((h // 4, w // 4), np.int16)
+    yc = np.zeros(16, np.float64)
+    err = lib.hmo_obf_prepass(Y.ctypes.data, w, h, w, obf.ctypes.data, yc.ctypes.data)
+    assert err == 0, "amplitude beyond the reference's bucket array"
+    return obf, yc
