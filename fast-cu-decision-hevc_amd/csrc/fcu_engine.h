@@ -192,7 +192,7 @@ struct Shared {
   uint8_t ref[264], reff[264];
   uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
   union {                                           /* never live at the same time */
-    int16_t lane_abs[MAXVC][16];                    /* per-lane |level| list of the coefficient group being coded */
+    int16_t lane_abs[MAXVC][32];                    /* per lane: |level| list of the coefficient group being coded [0..15], the group's levels [16..31] */
     int32_t colsum[128];                            /* availability flags of build_ref / chroma_leaf_refs5 */
     RdoqRec rq_rec[16];                             /* serial RDOQ: records of the coefficient group in flight */
   };
@@ -409,10 +409,18 @@ FCU_DEV FCU_INLINE void code_coeff_body(int c, const int16_t *coef, int st, int 
     int lastNZ = -1, firstNZ = 16, escape = 0;
     if (scanPosSig == scanPosLast) { absCoeff[0] = (int16_t)iabs(lastVal); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgpos = scanCG[sub], cgy = cgpos / wg, cgx = cgpos - cgy * wg;
+    /* the group's sixteen levels: one round of loads, parked in LDS for the serial walk below */
+    int16_t *stage = absCoeff + 16;
+    int any = 0;
+    {
+      int lv[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) lv[k] = coefg[(subPos + k) * st];
+#pragma unroll
+      for (int k = 0; k < 16; k++) { any |= lv[k]; stage[k] = (int16_t)lv[k]; }
+    }
     if (sub == lastSet || sub == 0) cgflag |= 1ull << cgpos;
     else {
-      int any = 0;
-      for (int k = 0; k < 16; k++) any |= coefg[(subPos + k) * st];
       if (any) cgflag |= 1ull << cgpos;
       FCU_BIN(any != 0, baseCG + sig_cg_ctx(cgflag, cgx, cgy, wg));
     }
@@ -420,13 +428,11 @@ FCU_DEV FCU_INLINE void code_coeff_body(int c, const int16_t *coef, int st, int 
       const int pattern = pattern_sig_ctx(cgflag, cgx, cgy, wg);
       const uint32_t cntBits = g_hot.cnt_bits[pattern];
       const int sigBase = baseSig + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
-      int ahead = scanPosSig >= subPos ? coefg[scanPosSig * st] : 0;
       /* a group of a TU > 4x4 uses three significance contexts (+ DC): their states stay in registers for the group */
       uint32_t s0 = 0, s1 = 0, s2 = 0;
       if (log2 > 2) { s0 = g_S.cab[c].ctx[sigBase]; s1 = g_S.cab[c].ctx[sigBase + 1]; s2 = g_S.cab[c].ctx[sigBase + 2]; }
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int v = ahead, sig = v != 0;
-        if (scanPosSig > subPos) ahead = coefg[(scanPosSig - 1) * st];       /* one ahead */
+        const int v = stage[scanPosSig - subPos], sig = v != 0;
         const int p4 = (int)((scan4 >> (4 * (scanPosSig - subPos))) & 15);     /* getSigCtxInc on the packed 4x4 scan (see rdoq) */
         if (scanPosSig > subPos || sub == 0 || numNonZero) {
           if (log2 == 2) FCU_BIN(sig, baseSig + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0));
