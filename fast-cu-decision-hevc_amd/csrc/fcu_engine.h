@@ -184,6 +184,8 @@ struct Scratch {
   RdoqRec r_rec[POOL]; double r_cg[MAXVC * 64];
 };
 
+struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
+
 /* per-chain LDS */
 struct Shared {
   /* hot coders, one LDS array so that coder ids index it directly:
@@ -213,6 +215,7 @@ struct Shared {
   int c_best_mode; uint32_t c_best_dist; double c_best_cost;
   uint32_t c_dist;
   int uni[8];
+  Env env;
 };
 
 enum { CAB_GOON = 0, CAB_CUR0 = 1, CAB_LANE0 = 1 + (MAXDEPTH + 1) };
@@ -221,7 +224,9 @@ static Shared g_S;
 #else
 __shared__ Shared g_S;
 #endif
-struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
+/* the wave's environment lives in LDS (g_S.env): non-inlined functions fetch it (to scalar registers) instead of
+ * receiving it as six vector-register arguments that would be spilled around every call */
+FCU_DEV Env env_get() { return FCU_UNI(g_S.env); }
 FCU_DEV Cabac *slot_ptr(const Env E, int d, int ci) { return ci == CI_CURR_BEST ? &g_S.cab[CAB_CUR0 + d] : &E.G->slots[d][ci]; }
 
 /* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
@@ -880,9 +885,9 @@ FCU_DEV int unit_available(const Env E, int lx, int ly, int cx, int cy)
 
 /* Reference samples of a block (initAdiPatternChType + fillReferenceSamples + smoothing,
  * TComPattern.cpp:104-521) -> g_S.ref (unfiltered), g_S.reff (filtered, luma only), g_S.dc. */
-FCU_DEV FCU_NOINLINE void build_ref(Env E, int comp, int px, int py, int log2, int wantFilt)
+FCU_DEV FCU_NOINLINE void build_ref(int comp, int px, int py, int log2, int wantFilt)
 {
-  E = FCU_UNI(E); comp = FCU_UNI(comp); px = FCU_UNI(px); py = FCU_UNI(py); log2 = FCU_UNI(log2); wantFilt = FCU_UNI(wantFilt);
+  const Env E = env_get(); comp = FCU_UNI(comp); px = FCU_UNI(px); py = FCU_UNI(py); log2 = FCU_UNI(log2); wantFilt = FCU_UNI(wantFilt);
   const int N = 1 << log2, sh = comp ? 1 : 0, unit = 4 >> sh, total = 4 * N + 1;
   const int lx0 = px << sh, ly0 = py << sh;
   const uint8_t *rec = E.C->rec[comp]; const int stride = E.C->stride[comp];
@@ -1047,9 +1052,9 @@ FCU_DEV void code_luma_dir_bits(int c, int dir, const int *preds)
   cab_bin(c, predIdx != -1, CTX_INTRA_LUMA);
   cab_ep(c, predIdx != -1 ? (predIdx ? 2 : 1) : 5);
 }
-FCU_DEV FCU_NOINLINE void code_intra_dir_luma(Env E, int c, const CuObj *cu, int part, int multiple)
+FCU_DEV FCU_NOINLINE void code_intra_dir_luma(int c, const CuObj *cu, int part, int multiple)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); part = FCU_UNI(part); multiple = FCU_UNI(multiple);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); part = FCU_UNI(part); multiple = FCU_UNI(multiple);
   int preds[4][3], predIdx[4];
   const int partNum = multiple ? (cu->part_size[part] == SIZE_NxN ? 4 : 1) : 1;
   const int partOffset = (NPART >> (cu->depth[part] << 1)) >> 2;
@@ -1067,9 +1072,9 @@ FCU_DEV void code_intra_dir_chroma(int c, int dir)       /* TEncSbac.cpp:698-725
 FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
 
 /* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
-FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(Env E, int c, const CuObj *cu, TU root, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, TU root, int bLuma, int bChroma)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1095,9 +1100,9 @@ FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(Env E, int c, const CuObj *cu, TU ro
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void enc_coeff_qt(Env E, int c, const CuObj *cu, TU root, int comp, int realCoeff)
+FCU_DEV FCU_NOINLINE void enc_coeff_qt(int c, const CuObj *cu, TU root, int comp, int realCoeff)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1123,28 +1128,28 @@ FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, 
 {
   if (bLuma) {
     if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, cu->part_size[0] == SIZE_2Nx2N, CTX_PARTSIZE);
-    if (cu->part_size[0] == SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(E, c, cu, 0, 0); }
-    else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(E, c, cu, part, 0); }
+    if (cu->part_size[0] == SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(c, cu, 0, 0); }
+    else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(c, cu, part, 0); }
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
-FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(Env E, int c, const CuObj *cu, TU tu, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(int c, const CuObj *cu, TU tu, int bLuma, int bChroma)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   cab_reset_bits(c);
   enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
-  enc_subdiv_cbf_qt(E, c, cu, tu, bLuma, bChroma);
-  if (bLuma) enc_coeff_qt(E, c, cu, tu, 0, 0);
-  if (bChroma) { enc_coeff_qt(E, c, cu, tu, 1, 0); enc_coeff_qt(E, c, cu, tu, 2, 0); }
+  enc_subdiv_cbf_qt(c, cu, tu, bLuma, bChroma);
+  if (bLuma) enc_coeff_qt(c, cu, tu, 0, 0);
+  if (bChroma) { enc_coeff_qt(c, cu, tu, 1, 0); enc_coeff_qt(c, cu, tu, 2, 0); }
   return cab_bits(c);
 }
 
 /* xGetIntraBitsQT (luma only) for the un-split TU that tu_trial() has just coded: the same bins as
  * intra_bits_qt() on a leaf, with the PU's MPM list from the RMD (g_S.preds, same intra_dir_predictor call)
  * and the levels still in scan order in the trial buffers */
-FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(Env E, int c, const CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, TU tu)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
   const int part = tu.part, partSize = cu->part_size[0], log2 = tu.log2;
   cab_reset_bits(c);
   if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
@@ -1159,9 +1164,9 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(Env E, int c, const CuObj *cu, TU t
 }
 
 /* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
-FCU_DEV FCU_NOINLINE void encode_transform(Env E, int c, const CuObj *cu, int cuPart, TU root)
+FCU_DEV FCU_NOINLINE void encode_transform(int c, const CuObj *cu, int cuPart, TU root)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); root = FCU_UNI(root);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); root = FCU_UNI(root);
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1201,18 +1206,18 @@ FCU_DEV FCU_NOINLINE void encode_transform(Env E, int c, const CuObj *cu, int cu
 FCU_DEV void encode_cu_syntax(const Env E, int c, const CuObj *cu, int cuPart, int depth)   /* TEncCu.cpp:2117-2141 / 1753-1778 */
 {
   if (depth == MAXDEPTH) cab_bin(c, cu->part_size[cuPart] == SIZE_2Nx2N, CTX_PARTSIZE);
-  code_intra_dir_luma(E, c, cu, cuPart, 1);
+  code_intra_dir_luma(c, cu, cuPart, 1);
   code_intra_dir_chroma(c, cu->intra_dir[1][cuPart]);
   TU root; tu_root(root, depth);
-  encode_transform(E, c, cu, cuPart, root);
+  encode_transform(c, cu, cuPart, root);
 }
 
 /* ======================================================================================== */
 /* CU object helpers (cooperative)                                                           */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void cu_init(Env E, CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
+FCU_DEV FCU_NOINLINE void cu_init(CuObj *cu, int depth, int x, int y, int zidx)       /* initEstData / initSubCU */
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); depth = FCU_UNI(depth); x = FCU_UNI(x); y = FCU_UNI(y); zidx = FCU_UNI(zidx);
+  const Env E = env_get(); cu = FCU_UNI(cu); depth = FCU_UNI(depth); x = FCU_UNI(x); y = FCU_UNI(y); zidx = FCU_UNI(zidx);
   const int n = NPART >> (2 * depth), s = CTU >> depth;
   FCU_FOR_LANES {
     if (lane == 0) { cu->cost = FCU_MAX_DOUBLE; cu->dist = 0; cu->bits = 0; cu->bins = 0; cu->depth_cu = depth; cu->x = x; cu->y = y; cu->zidx = zidx; cu->nparts = n; }
@@ -1226,9 +1231,9 @@ FCU_DEV FCU_NOINLINE void cu_init(Env E, CuObj *cu, int depth, int x, int y, int
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_part_from(Env E, CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
+FCU_DEV FCU_NOINLINE void cu_copy_part_from(CuObj *dst, const CuObj *src, int partUnitIdx)   /* copyPartFrom */
 {
-  E = FCU_UNI(E); dst = FCU_UNI(dst); src = FCU_UNI(src); partUnitIdx = FCU_UNI(partUnitIdx);
+  const Env E = env_get(); dst = FCU_UNI(dst); src = FCU_UNI(src); partUnitIdx = FCU_UNI(partUnitIdx);
   const int n = src->nparts, off = partUnitIdx * n;
   FCU_FOR_LANES {
     if (lane == 0) { dst->dist += src->dist; dst->bits += src->bits; dst->bins += src->bins; }
@@ -1243,9 +1248,9 @@ FCU_DEV FCU_NOINLINE void cu_copy_part_from(Env E, CuObj *dst, const CuObj *src,
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void cu_copy_to_pic(Env E, const CuObj *cu)                             /* copyToPic */
+FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                             /* copyToPic */
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu);
+  const Env E = env_get(); cu = FCU_UNI(cu);
   fcu_ctu_out *p = &E.C->out[E.cur_ctu];
   const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
   FCU_FOR_LANES {
@@ -1283,9 +1288,9 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(Env E, const CuObj *cu)                
     }
   }
 }
-FCU_DEV FCU_NOINLINE void copy_reco_to_pic(Env E, const Yuv *r, int x, int y, int s)
+FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Yuv *r, int x, int y, int s)
 {
-  E = FCU_UNI(E); r = FCU_UNI(r); x = FCU_UNI(x); y = FCU_UNI(y); s = FCU_UNI(s);
+  const Env E = env_get(); r = FCU_UNI(r); x = FCU_UNI(x); y = FCU_UNI(y); s = FCU_UNI(s);
   FCU_FOR_LANES {
     for (int c = 0; c < 3; c++) {
       const int sh = c ? 1 : 0, bs = c ? 32 : 64, w = E.C->p.width >> sh, h = E.C->p.height >> sh;
@@ -1300,9 +1305,9 @@ FCU_DEV FCU_NOINLINE void copy_reco_to_pic(Env E, const Yuv *r, int x, int y, in
 /* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
 /* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, int save1load2)
+FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, TU tu, int comp, int cab, int save1load2)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp); cab = FCU_UNI(cab); save1load2 = FCU_UNI(save1load2);
+  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp); cab = FCU_UNI(cab); save1load2 = FCU_UNI(save1load2);
   Scratch *G = E.G; const Params &P = E.C->p;
   if (comp && tu.cw == 0) { FCU_SERIAL { g_S.t_dist = 0; g_S.t_abs = 0; g_S.t_lsp = -1; } return; }
   FCU_TIC(t11_);
@@ -1322,7 +1327,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
 
   if (save1load2 != 2) {
     const int filt = use_filtered_ref(mode, log2, comp == 0);
-    build_ref(E, comp, px, py, log2, filt);
+    build_ref(comp, px, py, log2, filt);
     FCU_FOR_LANES {
       const uint8_t *r = filt ? g_S.reff : g_S.ref; const int dc = g_S.dc;
       if (lane == 0) g_S.t_last = -1;
@@ -1397,9 +1402,9 @@ FCU_DEV FCU_NOINLINE void tu_trial(Env E, CuObj *cu, TU tu, int comp, int cab, i
 }
 
 /* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
-FCU_DEV FCU_NOINLINE void store_intra_result_qt(Env E, TU tu, int comp)
+FCU_DEV FCU_NOINLINE void store_intra_result_qt(TU tu, int comp)
 {
-  E = FCU_UNI(E); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
+  const Env E = env_get(); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1407,9 +1412,9 @@ FCU_DEV FCU_NOINLINE void store_intra_result_qt(Env E, TU tu, int comp)
   const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
   FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
 }
-FCU_DEV FCU_NOINLINE void load_intra_result_qt(Env E, const CuObj *cu, TU tu, int comp)
+FCU_DEV FCU_NOINLINE void load_intra_result_qt(const CuObj *cu, TU tu, int comp)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
+  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, sh = comp ? 1 : 0, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1424,12 +1429,12 @@ FCU_DEV FCU_NOINLINE void load_intra_result_qt(Env E, const CuObj *cu, TU tu, in
 /* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to g_S.q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst, int reuseVc = -1)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int reuseVc = -1)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu); checkFirst = FCU_UNI(checkFirst); reuseVc = FCU_UNI(reuseVc);
+  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); checkFirst = FCU_UNI(checkFirst); reuseVc = FCU_UNI(reuseVc);
   Scratch *G = E.G; const Params &P = E.C->p;
-  const int d = cu->depth_cu, part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
-  const int partSize = cu->part_size[part];
+  const int d = FCU_UNI((int)cu->depth_cu), part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
+  const int partSize = FCU_UNI((int)cu->part_size[part]);
   const int checkFull = log2 <= LOG2_MAXTU;
   int checkSplit = log2 > min_tu_log2_in_cu(d, partSize);
   if (checkFirst && checkFull) checkSplit = 0;
@@ -1442,23 +1447,23 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst,
       FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
       for (int modeId = 0; modeId < 2; modeId++) {
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)modeId; }
-        tu_trial(E, cu, tu, 0, (CAB_GOON), modeId == 0 ? 1 : 2);
-        const uint32_t tmpDist = g_S.t_dist, tmpCbf = (cu->cbf[0][part] >> trDepth) & 1;
+        tu_trial(cu, tu, 0, (CAB_GOON), modeId == 0 ? 1 : 2);
+        const uint32_t tmpDist = FCU_UNI(g_S.t_dist), tmpCbf = FCU_UNI((uint32_t)((cu->cbf[0][part] >> trDepth) & 1));
         double tmpCost;
         if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
         else {
-          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(E, CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
-          tmpCost = rd_cost(P, g_S.vc_bits[0], tmpDist);
+          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
+          tmpCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], tmpDist));
         }
         if (tmpCost < singleCost) {
           singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
-          if (bestModeId == 0) { store_intra_result_qt(E, tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
+          if (bestModeId == 0) { store_intra_result_qt(tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
         }
         if (modeId == 0) FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)bestModeId; }
       if (bestModeId == 0) {
-        load_intra_result_qt(E, cu, tu, 0);
+        load_intra_result_qt(cu, tu, 0);
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_TEMP_BEST), lane); }
       }
     } else {
@@ -1468,7 +1473,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst,
         /* the un-split trial of the re-run (TEncSearch.cpp:2518-2586) repeats the first-pass trial of the same mode
          * from the same snapshot: take its levels, reconstruction, distortion, bits and coder state instead of
          * recomputing them (the candidate pools still hold them) */
-        const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = g_S.vc_abs[bv] > 0;
+        const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = FCU_UNI((int)(g_S.vc_abs[bv] > 0));
         FCU_FOR_LANES {
           for (int i = lane; i < n2; i += 64) {
             G->qt_coef[0][layer][tu.off_y + i] = (cbf && (i >> 4) <= (g_S.vc_last[bv] >> 4)) ? G->p_qscan[i * g_S.pu_nvc + bv] : (int16_t)0;
@@ -1477,13 +1482,13 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst,
           for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
           cab_copy(&g_S.cab[CAB_GOON], &g_S.cab[CAB_LANE0 + bv], lane);
         }
-        singleDist = g_S.vc_dist[bv]; singleCbf = (uint32_t)cbf; singleCost = g_S.vc_cost[bv];
+        singleDist = FCU_UNI(g_S.vc_dist[bv]); singleCbf = (uint32_t)cbf; singleCost = FCU_UNI(g_S.vc_cost[bv]);
       } else {
-        tu_trial(E, cu, tu, 0, (CAB_GOON), 0);
-        singleDist = g_S.t_dist;
-        if (checkSplit) singleCbf = (cu->cbf[0][part] >> trDepth) & 1;
-        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(E, CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
-        singleCost = rd_cost(P, g_S.vc_bits[0], singleDist);
+        tu_trial(cu, tu, 0, (CAB_GOON), 0);
+        singleDist = FCU_UNI(g_S.t_dist);
+        if (checkSplit) singleCbf = FCU_UNI((uint32_t)((cu->cbf[0][part] >> trDepth) & 1));
+        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
+        singleCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], singleDist));
       }
     }
   }
@@ -1495,16 +1500,16 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst,
       uint32_t splitCbf = 0;
       for (int i = 0; i < 4; i++) {
         TU c; tu_child(c, tu, i, 0);
-        recur_luma_qt<LEVEL + 1>(E, cu, c, checkFirst);
-        splitCbf |= (cu->cbf[0][c.part] >> c.tr_depth) & 1;
+        recur_luma_qt<LEVEL + 1>(cu, c, checkFirst);
+        splitCbf |= FCU_UNI((uint32_t)((cu->cbf[0][c.part] >> c.tr_depth) & 1));
       }
-      const uint32_t splitDist = g_S.q_dist[LEVEL + 1];
+      const uint32_t splitDist = FCU_UNI(g_S.q_dist[LEVEL + 1]);
       FCU_FOR_LANES {
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
         cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
-      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt(E, (CAB_GOON), cu, tu, 1, 0); } FCU_TOC(E, t12_, 12); }
-      const double splitCost = rd_cost(P, g_S.vc_bits[0], splitDist);
+      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt((CAB_GOON), cu, tu, 1, 0); } FCU_TOC(E, t12_, 12); }
+      const double splitCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], splitDist));
       if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; } return; }
       FCU_FOR_LANES {
         cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), lane);
@@ -1520,9 +1525,9 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(Env E, CuObj *cu, TU tu, int checkFirst,
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
-FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(Env E, CuObj *cu, TU root, Yuv *reco)
+FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(CuObj *cu, TU root, Yuv *reco)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); root = FCU_UNI(root); reco = FCU_UNI(reco);
+  const Env E = env_get(); cu = FCU_UNI(cu); root = FCU_UNI(root); reco = FCU_UNI(reco);
   Scratch *G = E.G;
   TU st[4]; int ci[4]; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -1585,12 +1590,12 @@ FCU_DEV uint32_t satd_unit(const uint8_t *org, int log2, int mode, int dc, int b
   return (uint32_t)(USZ == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
 }
 
-FCU_DEV FCU_NOINLINE void rmd(Env E, CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE void rmd(CuObj *cu, TU tu)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
-  build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
+  build_ref(0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   /* one (mode, Hadamard block) unit per lane, entirely in registers: no staging, no barrier between the stages */
   FCU_FOR_LANES { if (lane < 36) g_S.sad[lane] = 0; }
@@ -1640,9 +1645,9 @@ FCU_DEV FCU_NOINLINE void rmd(Env E, CuObj *cu, TU tu)
 /* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
 /* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
   const int partSize = cu->part_size[part];
@@ -1654,7 +1659,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
   const int useDst = log2 == 2;
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
   /* reference samples are shared by all candidates: the TU is the whole PU */
-  build_ref(E, 0, cu->x + tu.x, cu->y + tu.y, log2, 1);
+  build_ref(0, cu->x + tu.x, cu->y + tu.y, log2, 1);
   FCU_FOR_LANES {                                            /* prediction + residual per candidate */
     const int dc = g_S.dc;
     for (int i = lane; i < nc * n2; i += 64) {
@@ -1771,9 +1776,9 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(Env E, CuObj *cu, TU tu)
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void est_intra_pred_luma(Env E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu);
+  const Env E = env_get(); cu = FCU_UNI(cu);
   Scratch *G = E.G;
   const int d = cu->depth_cu, partSize = cu->part_size[0];
   const int initTrDepth = partSize == SIZE_2Nx2N ? 0 : 1, numPU = 1 << (2 * initTrDepth), qNumParts = cu->nparts >> 2;
@@ -1783,19 +1788,19 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(Env E, CuObj *cu)
   for (int pu = 0; pu < numPU; pu++) {
     TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
-    { FCU_TIC(t_); rmd(E, cu, tu); FCU_TOC(E, t_, 0); }
+    { FCU_TIC(t_); rmd(cu, tu); FCU_TOC(E, t_, 0); }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
-    if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(E, cu, tu); FCU_TOC(E, t_, 1); }
+    if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu); FCU_TOC(E, t_, 1); }
     else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
       FCU_SERIAL { g_S.pu_best_cost = FCU_MAX_DOUBLE; g_S.pu_best_mode = 0; g_S.pu_best_dist = 0; }
       const int nc = g_S.n_rd;
       for (int m = 0; m < nc; m++) {
         const int orgMode = g_S.rd_mode[m];
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
-        recur_luma_qt<0>(E, cu, tu, 1);
+        recur_luma_qt<0>(cu, tu, 1);
         if (g_S.q_cost[0] < g_S.pu_best_cost) {
           FCU_SERIAL { g_S.pu_best_mode = orgMode; g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
-          set_intra_result_luma_qt(E, cu, tu, recoT);
+          set_intra_result_luma_qt(cu, tu, recoT);
           FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
         }
       }
@@ -1806,10 +1811,10 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(Env E, CuObj *cu)
     if (log2 > min_tu_log2_in_cu(d, partSize)) {
       const int orgMode = g_S.pu_best_mode;
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
-      { FCU_TIC(t_); recur_luma_qt<0>(E, cu, tu, 0, singleTU ? g_S.pu_best_vc : -1); FCU_TOC(E, t_, 4); }
+      { FCU_TIC(t_); recur_luma_qt<0>(cu, tu, 0, singleTU ? g_S.pu_best_vc : -1); FCU_TOC(E, t_, 4); }
       if (g_S.q_cost[0] < g_S.pu_best_cost) {
         FCU_SERIAL { g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
-        set_intra_result_luma_qt(E, cu, tu, recoT);
+        set_intra_result_luma_qt(cu, tu, recoT);
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
       }
     }
@@ -1884,9 +1889,9 @@ FCU_DEV void chroma_leaf_refs5(const Env E, const CuObj *cu, int comp, int px, i
 }
 
 /* xGetIntraBitsQT(rTu, false, true) for mode slot m from the lane-private coder c (serial, one lane) */
-FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(Env E, int c, const CuObj *cu, int m, int mode, int16_t *absbuf)
+FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(int c, const CuObj *cu, int m, int mode, int16_t *absbuf)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu);
+  const Env E = env_get(); cu = FCU_UNI(cu);
   FCU_IN_LDS(absbuf);
   const ChromaModeBuf *B = &E.G->cm[m];
   cab_reset_bits(c);
@@ -1922,9 +1927,9 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(Env E, int c, const CuObj *cu, in
   return cab_bits(c);
 }
 
-FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
+FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
 {
-  E = FCU_UNI(E); cu = FCU_UNI(cu);
+  const Env E = env_get(); cu = FCU_UNI(cu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, n = cu->nparts, cs = (CTU >> d) >> 1;
   int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
@@ -2087,7 +2092,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
       }
       const int c = CAB_LANE0 + 5 + m;
       cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
-      g_S.vc_bits[m] = chroma_tree_bits(E, c, cu, m, modeList[m], g_S.lane_abs[lane]);
+      g_S.vc_bits[m] = chroma_tree_bits(c, cu, m, modeList[m], g_S.lane_abs[lane]);
       g_S.vc_cost[m] = rd_cost(P, g_S.vc_bits[m], g_S.cm_dist[m]);
     }
   }
@@ -2121,27 +2126,27 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(Env E, CuObj *cu)
 FCU_DEV CuObj *cu_best(const Env E, int d) { return &E.G->cu[d][g_S.best_idx[d]]; }
 FCU_DEV CuObj *cu_temp(const Env E, int d) { return &E.G->cu[d][1 - g_S.best_idx[d]]; }
 
-FCU_DEV FCU_NOINLINE void check_best_mode(Env E, int d)
+FCU_DEV FCU_NOINLINE void check_best_mode(int d)
 {
-  E = FCU_UNI(E); d = FCU_UNI(d);
+  const Env E = env_get(); d = FCU_UNI(d);
   const int change = cu_temp(E, d)->cost < cu_best(E, d)->cost;
   FCU_FOR_LANES {
     if (change) { cab_copy(slot_ptr(E, d, CI_NEXT_BEST), slot_ptr(E, d, CI_TEMP_BEST), lane); if (lane == 0) { g_S.best_idx[d] = 1 - g_S.best_idx[d]; g_S.reco_best_idx[d] = 1 - g_S.reco_best_idx[d]; } }
   }
 }
-FCU_DEV FCU_NOINLINE void check_rd_cost_intra(Env E, int d, int partSize)
+FCU_DEV FCU_NOINLINE void check_rd_cost_intra(int d, int partSize)
 {
-  E = FCU_UNI(E); d = FCU_UNI(d); partSize = FCU_UNI(partSize);
+  const Env E = env_get(); d = FCU_UNI(d); partSize = FCU_UNI(partSize);
   Scratch *G = E.G; const Params &P = E.C->p;
   CuObj *cu = cu_temp(E, d);
   const int n = cu->nparts, s = CTU >> d;
   FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTRA; } }
-  est_intra_pred_luma(E, cu);
+  est_intra_pred_luma(cu);
   {
     const Yuv *recoT = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES { uint8_t *p = E.C->rec[0] + cu->y * E.C->stride[0] + cu->x; const int rs = E.C->stride[0]; for (int i = lane; i < s * s; i += 64) p[(i / s) * rs + (i % s)] = recoT->y[(i / s) * 64 + (i % s)]; }
   }
-  { FCU_TIC(t_); est_intra_pred_chroma(E, cu); FCU_TOC(E, t_, 6); }
+  { FCU_TIC(t_); est_intra_pred_chroma(cu); FCU_TOC(E, t_, 6); }
   FCU_TIC(t7_);
   FCU_FOR_LANES {
     if (lane == 0) {
@@ -2153,13 +2158,13 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(Env E, int d, int partSize)
   }
   FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane);
   FCU_TOC(E, t7_, 7);
-  check_best_mode(E, d);
+  check_best_mode(d);
 }
 
 template <int D>
-FCU_DEV FCU_NOINLINE void compress_cu(Env E)
+FCU_DEV FCU_NOINLINE void compress_cu()
 {
-  E = FCU_UNI(E);
+  const Env E = env_get();
   Scratch *G = E.G; const Params &P = E.C->p;
   const CuObj *b0 = cu_best(E, D);
   const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
@@ -2173,10 +2178,10 @@ FCU_DEV FCU_NOINLINE void compress_cu(Env E)
         G->org[D].v[(i / h) * 32 + (i % h)] = E.C->org[2][(y / 2 + i / h) * E.C->stride[2] + x / 2 + (i % h)];
       }
     }
-    cu_init(E, cu_temp(E, D), D, x, y, zidx);
-    check_rd_cost_intra(E, D, SIZE_2Nx2N);
-    cu_init(E, cu_temp(E, D), D, x, y, zidx);
-    if (D == MAXDEPTH) { check_rd_cost_intra(E, D, SIZE_NxN); cu_init(E, cu_temp(E, D), D, x, y, zidx); }
+    cu_init(cu_temp(E, D), D, x, y, zidx);
+    check_rd_cost_intra(D, SIZE_2Nx2N);
+    cu_init(cu_temp(E, D), D, x, y, zidx);
+    if (D == MAXDEPTH) { check_rd_cost_intra(D, SIZE_NxN); cu_init(cu_temp(E, D), D, x, y, zidx); }
     FCU_SERIAL {
       CuObj *best = cu_best(E, D);
       if (best->cost != FCU_MAX_DOUBLE) {                   /* fork: TEncCu.cpp:1224 */
@@ -2187,17 +2192,17 @@ FCU_DEV FCU_NOINLINE void compress_cu(Env E)
       }
     }
   }
-  cu_init(E, cu_temp(E, D), D, x, y, zidx);
+  cu_init(cu_temp(E, D), D, x, y, zidx);
   if constexpr (D < MAXDEPTH) {
     const int nd = D + 1, hs = s >> 1, qn = NPART >> (2 * nd);
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
-      cu_init(E, &G->cu[nd][0], nd, sx, sy, zidx + i * qn);
-      cu_init(E, &G->cu[nd][1], nd, sx, sy, zidx + i * qn);
+      cu_init(&G->cu[nd][0], nd, sx, sy, zidx + i * qn);
+      cu_init(&G->cu[nd][1], nd, sx, sy, zidx + i * qn);
       if (sx < P.width && sy < P.height) {
         FCU_FOR_LANES cab_copy(slot_ptr(E, nd, CI_CURR_BEST), i == 0 ? slot_ptr(E, D, CI_CURR_BEST) : slot_ptr(E, nd, CI_NEXT_BEST), lane);
-        compress_cu<D + 1>(E);
-        cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
+        compress_cu<D + 1>();
+        cu_copy_part_from(cu_temp(E, D), cu_best(E, nd), i);
         {                                                    /* xCopyYuv2Tmp */
           const Yuv *src = &G->reco[nd][g_S.reco_best_idx[nd]]; Yuv *dst = &G->reco[D][1 - g_S.reco_best_idx[D]];
           FCU_FOR_LANES {
@@ -2207,8 +2212,8 @@ FCU_DEV FCU_NOINLINE void compress_cu(Env E)
           }
         }
       } else {
-        cu_copy_to_pic(E, cu_best(E, nd));
-        cu_copy_part_from(E, cu_temp(E, D), cu_best(E, nd), i);
+        cu_copy_to_pic(cu_best(E, nd));
+        cu_copy_part_from(cu_temp(E, D), cu_best(E, nd), i);
       }
     }
     FCU_SERIAL {
@@ -2217,16 +2222,16 @@ FCU_DEV FCU_NOINLINE void compress_cu(Env E)
       t->cost = rd_cost(P, t->bits, t->dist);
     }
     FCU_FOR_LANES cab_copy(slot_ptr(E, D, CI_TEMP_BEST), slot_ptr(E, nd, CI_NEXT_BEST), lane);
-    check_best_mode(E, D);
+    check_best_mode(D);
   }
-  cu_copy_to_pic(E, cu_best(E, D));
-  copy_reco_to_pic(E, &G->reco[D][g_S.reco_best_idx[D]], x, y, s);
+  cu_copy_to_pic(cu_best(E, D));
+  copy_reco_to_pic(&G->reco[D][g_S.reco_best_idx[D]], x, y, s);
 }
 
 /* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */
-FCU_DEV FCU_NOINLINE void encode_ctu(Env E, int c, const CuObj *ctu, int lastCtuOfSlice)
+FCU_DEV FCU_NOINLINE void encode_ctu(int c, const CuObj *ctu, int lastCtuOfSlice)
 {
-  E = FCU_UNI(E); c = FCU_UNI(c); ctu = FCU_UNI(ctu); lastCtuOfSlice = FCU_UNI(lastCtuOfSlice);
+  const Env E = env_get(); c = FCU_UNI(c); ctu = FCU_UNI(ctu); lastCtuOfSlice = FCU_UNI(lastCtuOfSlice);
   const Params &P = E.C->p;
   int stPart[4], stChild[4]; int sp = 0;
   stPart[0] = 0; stChild[0] = -1;
@@ -2292,7 +2297,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
   E.cur_ctu = ctuRsAddr; E.slice_start = sliceStart;
   fcu_ctu_out *out = &C->out[ctuRsAddr];
   const int x = (ctuRsAddr % C->w_ctu) * CTU, y = (ctuRsAddr / C->w_ctu) * CTU;
-  FCU_SERIAL { if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
+  FCU_SERIAL { g_S.env = E; if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
   FCU_FOR_LANES {                                            /* TComDataCU::initCtu defaults, TComDataCU.cpp:474-560 */
     for (int i = lane; i < NPART; i += 64) {
       out->depth[i] = 0; out->width[i] = CTU; out->height[i] = CTU; out->skip[i] = 0; out->part_size[i] = SIZE_NONE; out->pred_mode[i] = MODE_NONE;
@@ -2305,9 +2310,9 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
     cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
     if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
   }
-  cu_init(E, &G->cu[0][0], 0, x, y, 0);
-  cu_init(E, &G->cu[0][1], 0, x, y, 0);
-  compress_cu<0>(E);
+  cu_init(&G->cu[0][0], 0, x, y, 0);
+  cu_init(&G->cu[0][1], 0, x, y, 0);
+  compress_cu<0>();
   /* encodeCtu on [0][CI_CURR_BEST] (TEncSlice.cpp:1474-1487): replay the winner to advance the contexts */
   {
     const CuObj *view = cu_best(E, 0);                     /* what copyToPic has just published (whole CTU) */
@@ -2317,7 +2322,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
     FCU_TIC(t9_);
     FCU_SERIAL {
       cab_reset_bits((CAB_GOON));
-      encode_ctu(E, (CAB_GOON), view, ctuRsAddr == sliceEnd - 1);
+      encode_ctu((CAB_GOON), view, ctuRsAddr == sliceEnd - 1);
       cab_copy1(&C->state, &g_S.cab[CAB_GOON]);
     }
     FCU_TOC(E, t9_, 9);
