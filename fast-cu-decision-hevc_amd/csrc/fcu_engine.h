@@ -157,21 +157,21 @@ struct CuObj {
   int depth_cu, x, y, zidx, nparts;
   uint8_t depth[NPART]; int8_t part_size[NPART], pred_mode[NPART]; uint8_t tr_idx[NPART];
   uint8_t tskip[3][NPART], cbf[3][NPART], intra_dir[2][NPART];
-  int16_t coef[3][CTU * CTU];
+  alignas(16) int16_t coef[3][CTU * CTU];
 };
 struct Yuv { uint8_t y[64 * 64], u[32 * 32], v[32 * 32]; };
 /* state of one chroma-mode trial: the mode's own reconstruction (overlay of PicYuvRec inside the CU), levels, flags */
-struct ChromaModeBuf { uint8_t u[32 * 32], v[32 * 32]; int16_t coef[2][1024]; uint8_t cbf[2][NPART], tskip[2][NPART]; };
+struct ChromaModeBuf { uint8_t u[32 * 32], v[32 * 32]; alignas(16) int16_t coef[2][1024]; uint8_t cbf[2][NPART], tskip[2][NPART]; };
 
 /* RDOQ's per-coefficient locals as one record (TComTrQuant.cpp:2082-2095) */
 struct RdoqRec { double cc, cs, c0; int32_t up, dn, sd, du; };   /* pdCostCoeff, pdCostSig, pdCostCoeff0, rateIncUp/Down, sigRateDelta, deltaU */
 
 /* per-chain scratch in HBM (L2 resident working set) */
-struct Scratch {
+struct alignas(16) Scratch {
   CuObj cu[4][2];
   Yuv org[4], predt[4], reco[4][2];
   Yuv qt_rec[4];                                   /* m_pcQTTempTComYuv[layer] */
-  int16_t qt_coef[3][4][CTU * CTU];                /* m_ppcQTTempCoeff[comp][layer] */
+  alignas(16) int16_t qt_coef[3][4][CTU * CTU];                /* m_ppcQTTempCoeff[comp][layer] */
   int16_t ts_coef[3][1024]; Yuv ts_rec; uint8_t shared_pred[3][1024];
   uint8_t tmp_tr_idx[NPART], tmp_cbf[NPART], tmp_tskip[NPART];
   ChromaModeBuf cm[5];
@@ -370,7 +370,20 @@ FCU_DEV FCU_INLINE void code_coeff_body(int c, const int16_t *coef, int st, int 
   st = FCU_UNI(st); log2 = FCU_UNI(log2); comp = FCU_UNI(comp);
   FCU_IN_LDS(absCoeff);
   const FCU_HBM int16_t *coefg = (const FCU_HBM int16_t *)coef;
-  const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
+  const int ch = comp ? 1 : 0, N = 1 << log2; int n2 = N * N;
+  if (last < 0 && st == 1 && n2 >= 64) {                       /* contiguous levels: skip empty runs of four groups (128 bytes) with wide loads */
+    int q = (n2 >> 6) - 1;
+    for (; q >= 0; q--) {
+      uint32_t w[32];
+      __builtin_memcpy(w, __builtin_assume_aligned((const void *)(coef + q * 64), 16), 128);   /* TU-contiguous levels start on 32-byte boundaries */
+      uint32_t any = 0;
+#pragma unroll
+      for (int k = 0; k < 32; k++) any |= w[k];
+      if (any) break;
+    }
+    if (q < 0) return;
+    n2 = (q + 1) * 64;                                         /* the group-wise search below starts in the first non-empty run */
+  }
   if (last < 0) {                                             /* find the last non-zero level, a group's sixteen loads at a time */
     for (int cg = (n2 >> 4) - 1; cg >= 0 && last < 0; cg--) {
       uint32_t nz = 0;
