@@ -97,7 +97,7 @@ template <class T> __device__ inline T fcu_uni(T v)
 
 /* hot tables mirrored in LDS (the per-bin cost/transition table is read once per context-coded bin and several
  * times per RDOQ coefficient; on-chip reads keep the vector-memory pipeline for the scratch traffic) */
-struct HotTables { uint32_t bin[256]; uint16_t scan[3][16 + 64]; uint8_t scan_cg8[3][4]; uint8_t ctx_ind_map4x4[16]; uint8_t group_idx[32];
+struct HotTables { uint32_t bin[256]; uint16_t scan[3][16]; uint8_t scan_cg8[3][4]; uint8_t ctx_ind_map4x4[16]; uint8_t group_idx[32];
                    uint64_t scan4_nib[3], map4_nib; uint32_t cnt_bits[4]; };   /* 4x4 scans / 4x4 sig-ctx map as nibbles, sig-ctx counts per pattern as 2-bit fields */
 #ifdef FCU_EMU
 static HotTables g_hot;
@@ -123,7 +123,8 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
        CTX_TSKIP = 157, NCTX = 160 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
-enum { MAXVC = 20, POOL = 5120 };   /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
+enum { MAXVC = 20, MAXLC = 16, POOL = 5120 };   /* MAXVC candidate variants of a batch, MAXLC lane-private coders (the bit count runs in rounds) */
+/* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
 #define FCU_MAX_DOUBLE 1.7e+308
 
 /* coder state copied by TEncSbac::load/store (TEncSbac.cpp:397-426) */
@@ -190,21 +191,29 @@ struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
 struct Shared {
   /* hot coders, one LDS array so that coder ids index it directly:
    * [CAB_GOON] go-on coder, [CAB_CUR0+d] = [depth][CI_CURR_BEST], [CAB_LANE0+k] lane-private trial coders */
-  Cabac cab[1 + (MAXDEPTH + 1) + MAXVC];
-  uint8_t ref[264], reff[264];
-  uint8_t ref5[5][68], ref5b[5][68]; int dc5[5]; uint32_t cm_dist[5];   /* chroma: per-mode reference samples (N <= 16) */
+  Cabac cab[1 + (MAXDEPTH + 1) + MAXLC];
+  union {                                           /* luma reference samples / scratch copy of the chroma sets: never live together */
+    struct { uint8_t ref[264], reff[264]; };
+    uint8_t ref5b[5][68];
+  };
+  uint8_t ref5[5][68]; int dc5[5]; uint32_t cm_dist[5];     /* chroma: per-mode reference samples (N <= 16) */
   union {                                           /* never live at the same time */
-    int16_t lane_abs[MAXVC][32];                    /* per lane: |level| list of the coefficient group being coded [0..15], the group's levels [16..31] */
+    int16_t lane_abs[MAXLC][32];                    /* per lane: |level| list of the coefficient group being coded [0..15], the group's levels [16..31] */
     int32_t colsum[128];                            /* availability flags of build_ref / chroma_leaf_refs5 */
     RdoqRec rq_rec[16];                             /* serial RDOQ: records of the coefficient group in flight */
   };
-  int16_t rq_lv[16];                                /* serial RDOQ: levels of the coefficient group in flight */
-  uint32_t sad[36];
+  union {
+    int16_t rq_lv[16];                              /* serial RDOQ: levels of the coefficient group in flight */
+    uint32_t sad[36];                               /* RMD SATD per mode; [35] SSE accumulator of a TU trial */
+  };
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
   /* PU / TU mailbox written by serial blocks */
-  int rd_mode[12]; int n_rd;
-  int preds[3]; int n_mpm;
+  union {
+    struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
+    int uni[8];                                                       /* chroma leaf: transform-skip choice per mode */
+  };
+  uint8_t vc_slot[MAXVC];                           /* lane coder that holds a variant's state after the bit count */
   int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
   int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
@@ -214,7 +223,6 @@ struct Shared {
   /* chroma search */
   int c_best_mode; uint32_t c_best_dist; double c_best_cost;
   uint32_t c_dist;
-  int uni[8];
   Env env;
 };
 
@@ -398,7 +406,7 @@ FCU_DEV FCU_INLINE void code_coeff_body(int c, const int16_t *coef, int st, int 
 #define FCU_BIN(bin_, ctx_) do { const int cx_ = (ctx_); const uint32_t e_ = g_hot.bin[g_S.cab[c].ctx[cx_] * 2 + (bin_)]; nb++; fr += (uint64_t)(e_ >> 8); g_S.cab[c].ctx[cx_] = (uint8_t)e_; } while (0)
 #define FCU_EP(n_) do { const uint32_t n__ = (uint32_t)(n_); nb += n__; fr += (uint64_t)32768 * (uint64_t)n__; } while (0)
   if (P.transform_skip && log2 == 2) FCU_BIN(tsFlag, CTX_TSKIP + ch);
-  const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint16_t *scan = log2 == 2 ? &g_hot.scan[scanType][0] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   uint64_t cgflag = 0;
@@ -586,7 +594,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   const double errScale = P.err_scale[ch][log2 - 2];
   /* the reference clears all seven arrays; only entries at scan positions <= the last significant one are
    * ever read back (last-position search, group zero-out, sign hiding), and each of those is written below */
-  const uint16_t *scan = log2 <= 3 ? &g_hot.scan[scanType][log2 == 2 ? 0 : 16] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint16_t *scan = log2 == 2 ? &g_hot.scan[scanType][0] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
   const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
   const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
   const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
@@ -1493,7 +1501,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
             G->qt_rec[layer].y[(tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1))] = G->p_rec[bv * n2 + i];
           }
           for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
-          cab_copy(&g_S.cab[CAB_GOON], &g_S.cab[CAB_LANE0 + bv], lane);
+          cab_copy(&g_S.cab[CAB_GOON], &g_S.cab[CAB_LANE0 + g_S.vc_slot[bv]], lane);
         }
         singleDist = FCU_UNI(g_S.vc_dist[bv]); singleCbf = (uint32_t)cbf; singleCost = FCU_UNI(g_S.vc_cost[bv]);
       } else {
@@ -1667,7 +1675,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
   int checkTS = P.transform_skip && log2 == 2;
   if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
   const int nc = g_S.n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
-  FCU_CHECK(nvc <= MAXVC && nvc * n2 <= POOL);
+  FCU_CHECK(nvc <= MAXVC && nvc * n2 <= POOL && (MAXLC % 2) == 0);
   const int qbits = rdoq_qbits(log2, P.qp), qscale = k_quant_scales[P.qp % 6];
   const int useDst = log2 == 2;
   const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
@@ -1741,38 +1749,50 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
     });
   }
   FCU_TIC(t3_);
-  FCU_FOR_LANES {                                            /* bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT */
-    const int vc = lane;
-    if (vc < nvc) {
-      const int cnd = vc / tsv, ts = vc % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[vc] > 0;
-      double cost;
-      if (ts && !cbf) cost = FCU_MAX_DOUBLE;                 /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
-      else {
-        const int c = CAB_LANE0 + lane;
-        cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
-        cab_reset_bits(c);
-        if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
-        code_luma_dir_bits(c, mode, g_S.preds);
-        if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
-          cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
-        cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-        if (cbf) code_coeff_nxn<0>(c, G->p_qscan + vc, nvc, g_S.vc_lsp[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[lane]);
-        g_S.vc_bits[vc] = cab_bits(c);
-        cost = rd_cost(P, g_S.vc_bits[vc], g_S.vc_dist[vc]);
+  /* Bits of (header, subdiv, cbf, coefficients): xGetIntraBitsQT, one variant per lane on MAXLC lane-private coders.
+   * More than MAXLC variants (a 4x4 PU with 9-10 candidates x 2) take a second round; it reuses coder slots, but
+   * never the one of the best variant so far: the re-run of the winner (recur_luma_qt) takes its coder state from there. */
+  for (int vbase = 0; vbase < nvc; vbase += MAXLC) {
+    const int slotBase = vbase ? (g_S.vc_slot[g_S.pu_best_vc] + 1) % MAXLC : 0;
+#if defined(FCU_EMU) && defined(FCU_EMU_TRACE_ROUNDS)
+    if (vbase) fprintf(stderr, "second bit-count round: %d variants\n", nvc);
+#endif
+    FCU_FOR_LANES {
+      const int vc = vbase + lane;
+      if (lane < MAXLC && vc < nvc) {
+        const int cnd = vc / tsv, ts = vc % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[vc] > 0;
+        const int slot = (slotBase + lane) % MAXLC;
+        double cost;
+        g_S.vc_slot[vc] = (uint8_t)slot;
+        if (ts && !cbf) cost = FCU_MAX_DOUBLE;               /* TS with CBF 0 is forbidden, TEncSearch.cpp:1503-1507 */
+        else {
+          const int c = CAB_LANE0 + slot;
+          cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
+          cab_reset_bits(c);
+          if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
+          code_luma_dir_bits(c, mode, g_S.preds);
+          if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
+            cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
+          cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+          if (cbf) code_coeff_nxn<0>(c, G->p_qscan + vc, nvc, g_S.vc_lsp[vc], log2, 0, coef_scan_idx(mode, log2, 0), ts, P, g_S.lane_abs[slot]);
+          g_S.vc_bits[vc] = cab_bits(c);
+          cost = rd_cost(P, g_S.vc_bits[vc], g_S.vc_dist[vc]);
+        }
+        g_S.vc_cost[vc] = cost;
       }
-      g_S.vc_cost[vc] = cost;
+    }
+    FCU_SERIAL {                                             /* strict '<', earlier candidate wins ties; candidates coded so far */
+      const int ncDone = ((vbase + MAXLC < nvc) ? vbase + MAXLC : nvc) / tsv;
+      double best = FCU_MAX_DOUBLE; int bv = 0;
+      for (int cnd = 0; cnd < ncDone; cnd++) {
+        int v = cnd * tsv; double c = g_S.vc_cost[v];
+        if (tsv == 2 && g_S.vc_cost[v + 1] < c) { v = v + 1; c = g_S.vc_cost[v]; }
+        if (c < best) { best = c; bv = v; }
+      }
+      g_S.pu_nvc = nvc; g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
     }
   }
   FCU_TOC(E, t3_, 3);
-  FCU_SERIAL {                                               /* strict '<', earlier candidate wins ties */
-    double best = FCU_MAX_DOUBLE; int bv = 0;
-    for (int cnd = 0; cnd < nc; cnd++) {
-      int v = cnd * tsv; double c = g_S.vc_cost[v];
-      if (tsv == 2 && g_S.vc_cost[v + 1] < c) { v = v + 1; c = g_S.vc_cost[v]; }
-      if (c < best) { best = c; bv = v; }
-    }
-    g_S.pu_nvc = nvc; g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
-  }
   {                                                          /* xSetIntraResultLumaQT + decision snapshot */
     const int bv = g_S.pu_best_vc, ts = bv % tsv, cbf = g_S.vc_abs[bv] > 0;
     Yuv *reco = &G->reco[d][1 - g_S.reco_best_idx[d]];
@@ -2276,7 +2296,7 @@ FCU_DEV void load_hot_tables()
 {
   FCU_FOR_LANES {
     for (int i = lane; i < 256; i += 64) g_hot.bin[i] = k_bin[i];
-    for (int i = lane; i < 3 * 80; i += 64) { const int t = i / 80, j = i % 80; g_hot.scan[t][j] = j < 16 ? k_scan[k_scan_off[t * 4 + 0] + j] : k_scan[k_scan_off[t * 4 + 1] + j - 16]; }
+    for (int i = lane; i < 3 * 16; i += 64) { const int t = i / 16, j = i % 16; g_hot.scan[t][j] = k_scan[k_scan_off[t * 4 + 0] + j]; }
     if (lane < 12) g_hot.scan_cg8[lane / 4][lane % 4] = k_scan_cg[k_scan_cg_off[(lane / 4) * 4 + 1] + lane % 4];
     if (lane < 16) g_hot.ctx_ind_map4x4[lane] = k_ctx_ind_map4x4[lane];
     if (lane < 32) g_hot.group_idx[lane] = k_group_idx[lane];

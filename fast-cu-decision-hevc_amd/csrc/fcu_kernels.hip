@@ -210,6 +210,14 @@ int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bit
   return FCU_OK;
 }
 
+/* diagnostic: resident workgroups (= chains) per CU the runtime grants the engine kernel */
+int fcu_chains_per_cu(void)
+{
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fcu_ctu_engine, 64, 0) != hipSuccess) return -1;
+  return n;
+}
+
 /* ---- fork pre-pass: OBF maps of n luma planes ------------------------------------------------------------ */
 int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc, float *kernel_ms2, void *hip_stream)
 {

@@ -49,11 +49,12 @@ CTU_OUT_BYTES = C.sizeof(CtuOut)
 
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
-           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass"]
+           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu"]
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfcu.so")
+    # FCU_LIB: another build of the same library next to it (diagnostic variants: profiling timers, register budgets)
+    return os.path.join(_HERE, os.environ.get("FCU_LIB", "libfcu.so"))
 
 
 _lib = None

@@ -109,6 +109,8 @@ int  fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17);
  * the histogram and the counting kernel.  Synchronous (the threshold fit runs on the host between the kernels). */
 int  fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc,
                      float *kernel_ms2, void *hip_stream);
+/* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
+int  fcu_chains_per_cu(void);
 const char *fcu_last_error(void);
 
 #ifdef __cplusplus
