@@ -213,6 +213,7 @@ struct Shared {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
     int uni[8];                                                       /* chroma leaf: transform-skip choice per mode */
   };
+  uint32_t est[NCTX * 2];                            /* estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
   uint8_t vc_slot[MAXVC];                           /* lane coder that holds a variant's state after the bit count */
   int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
   int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
@@ -311,6 +312,9 @@ FCU_DEV void cab_trm(int cid, int bin) { FCU_CB.bins++; FCU_CB.frac += (uint64_t
 FCU_DEV void cab_reset_bits(int cid) { FCU_CB.frac &= 32767; FCU_CB.bins = 0; }
 FCU_DEV uint32_t cab_bits(int cid) { return (uint32_t)(FCU_CB.frac >> 15); }
 FCU_DEV int ctx_bits(int cid, int ctx, int bin) { return (int)(g_hot.bin[FCU_CB.ctx[ctx] * 2 + bin] >> 8); }
+/* TEncSbac::estBit: the costs of both bins of every context of coder `cid`, one LDS word each; called by all lanes
+ * in the phase before RDOQ (the contexts are frozen while RDOQ runs) */
+FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX * 2; i += 64) g_S.est[i] = g_hot.bin[FCU_CB.ctx[i >> 1] * 2 + (i & 1)] >> 8; }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -549,17 +553,18 @@ FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint
   else rate = 0;
   return rate;
 }
-FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
+template <class CB>
+FCU_DEV uint32_t coded_level(CB cb, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
                              int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, const LevelBits &lb,
                              uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last)
 {                                                          /* xGetCodedLevel, TComTrQuant.cpp:2738-2794 */
   double currCostSig = 0; uint32_t bestAbs = 0;
   if (!last && maxAbsLevel < 3) {
-    *codedCostSig = lambda * (double)ctx_bits(c, ctxSig, 0);
+    *codedCostSig = lambda * (double)cb(ctxSig, 0);
     *codedCost = *codedCost0 + *codedCostSig;
     if (maxAbsLevel == 0) return bestAbs;
   } else *codedCost = FCU_MAX_DOUBLE;
-  if (!last) currCostSig = lambda * (double)ctx_bits(c, ctxSig, 1);
+  if (!last) currCostSig = lambda * (double)cb(ctxSig, 1);
   const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
   for (int a = (int)maxAbsLevel; a >= (int)minAbs; a--) {
     double err = (double)(levelDouble - ((int32_t)a << qbits));
@@ -577,7 +582,8 @@ FCU_DEV uint32_t coded_level(int c, double lambda, double *codedCost, double *co
  * zero by construction and the consumers know topNZ.  Returns uiAbsSum and the scan position of the last
  * non-zero level (-1: none). */
 struct RdoqOut { int abs_sum, last; };
-template <int SER>
+/* EST = 1: the caller has built g_S.est for coder `c` (est_build); EST = 0: costs are looked up in the coder itself */
+template <int SER, int EST>
 FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
 {
   const Params &P = *FCU_UNI(&P_);
@@ -587,6 +593,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
   const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
   FCU_HBM RdoqRec *recg = (FCU_HBM RdoqRec *)rec; FCU_HBM double *cgg = (FCU_HBM double *)costCGSig;
+  auto cb = [&](int ctx, int bin) -> int { return EST ? (int)g_S.est[ctx * 2 + bin] : ctx_bits(c, ctx, bin); };
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? P.qp_c : P.qp;
   const int qbits = rdoq_qbits(log2, qp);
@@ -628,8 +635,8 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
     const int sigBase = sigOff + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
     int b00 = 0, b01 = 0, b02 = 0, b10 = 0, b11 = 0, b12 = 0;
     if (log2 > 2) {
-      b00 = ctx_bits(c, sigBase, 0); b01 = ctx_bits(c, sigBase + 1, 0); b02 = ctx_bits(c, sigBase + 2, 0);
-      b10 = ctx_bits(c, sigBase, 1); b11 = ctx_bits(c, sigBase + 1, 1); b12 = ctx_bits(c, sigBase + 2, 1);
+      b00 = cb(sigBase, 0); b01 = cb(sigBase + 1, 0); b02 = cb(sigBase + 2, 0);
+      b10 = cb(sigBase, 1); b11 = cb(sigBase + 1, 1); b12 = cb(sigBase + 2, 1);
     }
     const uint32_t cntBits = g_hot.cnt_bits[pattern];
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
@@ -649,12 +656,12 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
       }
       if (lastScanPos >= 0) {
         const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1;
-        if (oneCtx != g10Ctx) { g10 = ctx_bits(c, oneCtx, 0); g10Ctx = oneCtx; }
+        if (oneCtx != g10Ctx) { g10 = cb(oneCtx, 0); g10Ctx = oneCtx; }
         /* position inside the 4x4 group (raster) from the packed 4x4 scan; its significance context */
         const int p4 = (int)((scan4 >> (4 * posInCG)) & 15);
         int ctxSig, sbit0, sbit1;
-        if (log2 == 2) { ctxSig = sigOff + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0); sbit0 = ctx_bits(c, ctxSig, 0); sbit1 = ctx_bits(c, ctxSig, 1); }
-        else if (scanPos == 0) { ctxSig = sigOff; sbit0 = ctx_bits(c, ctxSig, 0); sbit1 = ctx_bits(c, ctxSig, 1); }
+        if (log2 == 2) { ctxSig = sigOff + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0); sbit0 = cb(ctxSig, 0); sbit1 = cb(ctxSig, 1); }
+        else if (scanPos == 0) { ctxSig = sigOff; sbit0 = cb(ctxSig, 0); sbit1 = cb(ctxSig, 1); }
         else { const int cnt = (int)((cntBits >> (2 * p4)) & 3); ctxSig = sigBase + cnt; sbit0 = cnt == 0 ? b00 : (cnt == 1 ? b01 : b02); sbit1 = cnt == 0 ? b10 : (cnt == 1 ? b11 : b12); }
         int sdel = 0, rup, rdn = 0;
         if (maxAbsLevel == 0) {                              /* xGetCodedLevel's early exit (:2752-2760); never the last position */
@@ -670,12 +677,12 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           continue;
         } else {
           const int absCtx = CTX_ABS + (int)ctxSet + c2;
-          LevelBits lb; lb.g10 = g10; lb.g11 = ctx_bits(c, oneCtx, 1); lb.g20 = ctx_bits(c, absCtx, 0); lb.g21 = ctx_bits(c, absCtx, 1);
+          LevelBits lb; lb.g10 = g10; lb.g11 = cb(oneCtx, 1); lb.g20 = cb(absCtx, 0); lb.g21 = cb(absCtx, 1);
           if (scanPos == lastScanPos)
-            level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+            level = coded_level(cb, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
                                 sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1);
           else {
-            level = coded_level(c, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+            level = coded_level(cb, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
                                 ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0);
             sdel = sbit1 - sbit0;
           }
@@ -713,19 +720,19 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
       if (cgScanPos) {
         if (((cgflag >> cgBlk) & 1) == 0) {
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
-          baseCost += lambda * (double)ctx_bits(c, ctxSig, 0) - rdSigCost;
-          cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
+          baseCost += lambda * (double)cb(ctxSig, 0) - rdSigCost;
+          cgg[cgScanPos * st] = lambda * (double)cb(ctxSig, 0);
         } else if (cgScanPos < cgLastScanPos) {
           if (nnzBeforePos0 == 0) { baseCost -= rdSigCost0; rdSigCost -= rdSigCost0; }
           double costZeroCG = baseCost;
           const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
-          baseCost += lambda * (double)ctx_bits(c, ctxSig, 1);
-          costZeroCG += lambda * (double)ctx_bits(c, ctxSig, 0);
-          cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 1);
+          baseCost += lambda * (double)cb(ctxSig, 1);
+          costZeroCG += lambda * (double)cb(ctxSig, 0);
+          cgg[cgScanPos * st] = lambda * (double)cb(ctxSig, 1);
           costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
           if (costZeroCG < baseCost) {
             cgflag &= ~(1ull << cgBlk); baseCost = costZeroCG;
-            cgg[cgScanPos * st] = lambda * (double)ctx_bits(c, ctxSig, 0);
+            cgg[cgScanPos * st] = lambda * (double)cb(ctxSig, 0);
             for (int posInCG = 15; posInCG >= 0; posInCG--) {
               const int scanPos = cgScanPos * 16 + posInCG;
               if (SER) { if (g_S.rq_lv[posInCG]) { g_S.rq_lv[posInCG] = 0; g_S.rq_rec[posInCG].cc = g_S.rq_rec[posInCG].c0; g_S.rq_rec[posInCG].cs = 0; } }
@@ -744,8 +751,8 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   if (lastScanPos < 0) { RdoqOut z = { 0, -1 }; return z; }
 
   double bestCost; int bestLastIdxP1 = 0;
-  bestCost = blockUncodedCost + lambda * (double)ctx_bits(c, cbfCtx, 0);
-  baseCost += lambda * (double)ctx_bits(c, cbfCtx, 1);
+  bestCost = blockUncodedCost + lambda * (double)cb(cbfCtx, 0);
+  baseCost += lambda * (double)cb(cbfCtx, 1);
   /* estLastSignificantPositionBit (TEncSbac.cpp:1863-1923) evaluated on demand */
   const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
   const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = g_hot.group_idx[N - 1];
@@ -766,10 +773,10 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
           const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
           const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
           int bxs = 0, bys = 0;
-          for (int k = 0; k < gx; k++) bxs += ctx_bits(c, lbx + (k >> lsh), 1);
-          if (gx < lgmax) bxs += ctx_bits(c, lbx + (gx >> lsh), 0);
-          for (int k = 0; k < gy; k++) bys += ctx_bits(c, lby + (k >> lsh), 1);
-          if (gy < lgmax) bys += ctx_bits(c, lby + (gy >> lsh), 0);
+          for (int k = 0; k < gx; k++) bxs += cb(lbx + (k >> lsh), 1);
+          if (gx < lgmax) bxs += cb(lbx + (gx >> lsh), 0);
+          for (int k = 0; k < gy; k++) bys += cb(lby + (k >> lsh), 1);
+          if (gy < lgmax) bys += cb(lby + (gy >> lsh), 0);
           double r = (double)(bxs + bys);                                  /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
           if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
           if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
@@ -1372,10 +1379,10 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, TU tu, int comp, int cab, int save
   /* forward transform; the coefficients go to RDOQ as sign * lLevelDouble in scan order */
   const int scanType = coef_scan_idx(mode, log2, comp), qbits = rdoq_qbits(log2, qp), qscale = k_quant_scales[qp % 6];
   const uint16_t *iscan = k_iscan + k_scan_off[scanType * 4 + log2 - 2];
-  if (useTS) { FCU_FOR_LANES { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } } }
+  if (useTS) { FCU_FOR_LANES { est_build(cab, lane); for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } } }
   else {
     FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi, useDst, i); }); }
-    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<decltype(L)::value>(G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
+    FCU_FOR_LANES { est_build(cab, lane); by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<decltype(L)::value>(G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
   }
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
@@ -1383,7 +1390,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, TU tu, int comp, int cab, int save
       FCU_TIC(t8_);
       RdoqRec *rrec = G->r_rec; double *rcg = G->r_cg;
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      const RdoqOut o = rdoq<1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
+      const RdoqOut o = rdoq<1, 1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
       g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
       E.C->n_tu_trials++;
       FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */
@@ -1692,6 +1699,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
   }
   FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + cnd * n2, useDst, i - cnd * n2); } }); }
   FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
+    est_build(CAB_CUR0 + d, lane);
     by_log2(log2, [&](auto L) {
       for (int i = lane; i < nvc * n2; i += 64) {
         const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
@@ -1709,7 +1717,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
       const int mode = g_S.rd_mode[lane / tsv];
       RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      const RdoqOut o = rdoq<0>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
+      const RdoqOut o = rdoq<0, 1>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
       g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
       g_S.vc_dist[lane] = 0;
     }
@@ -2021,7 +2029,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
                 const int m = lane / tsv;
                 const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
                 RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
-                const RdoqOut o = rdoq<0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
+                const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
                 g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
                 g_S.vc_dist[lane] = 0;
               }
