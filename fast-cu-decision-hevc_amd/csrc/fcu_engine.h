@@ -186,6 +186,8 @@ struct alignas(16) Scratch {
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
+/* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
+struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
 
 /* per-chain LDS */
 struct Shared {
@@ -222,9 +224,12 @@ struct Shared {
   /* RQT recursion results */
   double q_cost[4]; uint32_t q_dist[4];
   /* chroma search */
-  int c_best_mode; uint32_t c_best_dist; double c_best_cost;
+  int c_best_mode; uint32_t c_best_dist; double c_best_cost; int c_modes[5];
   uint32_t c_dist;
   Env env;
+  /* explicit stacks of the serial tree walkers (a private array indexed by the stack pointer would live in scratch memory) */
+  TU wk_st[4]; int wk_ci[4]; int wk_part[4], wk_child[4];
+  double cand_cost[12];                             /* RMD candidate costs (CandCostList, TEncSearch.cpp:2289) */
 };
 
 enum { CAB_GOON = 0, CAB_CUR0 = 1, CAB_LANE0 = 1 + (MAXDEPTH + 1) };
@@ -238,8 +243,6 @@ __shared__ Shared g_S;
 FCU_DEV Env env_get() { return FCU_UNI(g_S.env); }
 FCU_DEV Cabac *slot_ptr(const Env E, int d, int ci) { return ci == CI_CURR_BEST ? &g_S.cab[CAB_CUR0 + d] : &E.G->slots[d][ci]; }
 
-/* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
-struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
 
 /* ======================================================================================== */
 /* small helpers                                                                            */
@@ -1103,7 +1106,7 @@ FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir
 FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, TU root, int bLuma, int bChroma)
 {
   const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
-  TU st[4]; int ci[4]; int sp = 0;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
     const TU tu = st[sp];
@@ -1131,7 +1134,7 @@ FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, TU root, int
 FCU_DEV FCU_NOINLINE void enc_coeff_qt(int c, const CuObj *cu, TU root, int comp, int realCoeff)
 {
   const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
-  TU st[4]; int ci[4]; int sp = 0;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
     const TU tu = st[sp];
@@ -1195,7 +1198,7 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, TU tu)
 FCU_DEV FCU_NOINLINE void encode_transform(int c, const CuObj *cu, int cuPart, TU root)
 {
   const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); root = FCU_UNI(root);
-  TU st[4]; int ci[4]; int sp = 0;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
     const TU tu = st[sp];
@@ -1557,7 +1560,7 @@ FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(CuObj *cu, TU root, Yuv *reco
 {
   const Env E = env_get(); cu = FCU_UNI(cu); root = FCU_UNI(root); reco = FCU_UNI(reco);
   Scratch *G = E.G;
-  TU st[4]; int ci[4]; int sp = 0;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
     const TU tu = st[sp];
@@ -1644,7 +1647,7 @@ FCU_DEV FCU_NOINLINE void rmd(CuObj *cu, TU tu)
     const Cabac *cb = slot_ptr(E, d, CI_CURR_BEST);
     const uint64_t carry = cb->frac & 32767;               /* loadIntraDirMode + resetBits, TEncSearch.cpp:5313-5340 */
     int numFull = k_rd_mode_num[log2 - 2];
-    double candCost[12];
+    double *candCost = g_S.cand_cost;                    /* in LDS: the sorted insert indexes it with run-time subscripts */
     for (int i = 0; i < numFull; i++) candCost[i] = FCU_MAX_DOUBLE;
     for (int mode = 0; mode < 35; mode++) {
       int predIdx = -1;
@@ -1973,14 +1976,18 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
   const Env E = env_get(); cu = FCU_UNI(cu);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, n = cu->nparts, cs = (CTU >> d) >> 1;
-  int modeList[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };    /* getAllowedChromaDir, TComDataCU.cpp:1509-1533 */
-  { const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == modeList[i]) { modeList[i] = 34; break; } }
+  /* getAllowedChromaDir, TComDataCU.cpp:1509-1533; the list lives in LDS (it is indexed per element below) */
   FCU_FOR_LANES {
+    if (lane == 0) {
+      int ml[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+      const int luma = cu->intra_dir[0][0]; for (int i = 0; i < 4; i++) if (luma == ml[i]) { ml[i] = 34; break; }
+      for (int i = 0; i < 5; i++) g_S.c_modes[i] = ml[i];
+    }
     if (lane < 5) { cab_copy1(&g_S.cab[CAB_LANE0 + lane], slot_ptr(E, d, CI_CURR_BEST)); g_S.cm_dist[lane] = 0; }
     for (int i = lane; i < 5 * n; i += 64) { const int m = i / n, p = i - m * n; G->cm[m].cbf[0][p] = G->cm[m].cbf[1][p] = 0; G->cm[m].tskip[0][p] = G->cm[m].tskip[1][p] = 0; }
   }
   /* ---- walk the luma TU tree; chroma leaves in z-order ---- */
-  TU st[4]; int ci[4]; int sp = 0;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   tu_root(st[0], d); ci[0] = -1;
   while (sp >= 0) {
     if (ci[sp] < 0) {
@@ -2004,7 +2011,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
             FCU_FOR_LANES {
               for (int i = lane; i < 5 * n2; i += 64) {
                 const int m = i / n2, p = i - m * n2, y = p >> log2, x = p & (N - 1);
-                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
                 const int pr = pred_pixel(g_S.ref5[m], log2, mode, 0, g_S.dc5[m], x, y);
                 G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
               }
@@ -2014,7 +2021,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
               by_log2(log2, [&](auto L) {
                 for (int i = lane; i < nvc * n2; i += 64) {
                   const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
-                  const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                  const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
                   const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
                   const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + m * n2, 0, p);
                   const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
@@ -2027,7 +2034,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
             FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
               if (lane < nvc) {
                 const int m = lane / tsv;
-                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
                 RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
                 const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
                 g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
@@ -2040,7 +2047,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
               const DeqParams dq = deq_params(log2, P.qp_c);
               for (int i = lane; i < nvc * n2; i += 64) {
                 const int v = i / n2, p = i - v * n2, m = v / tsv;
-                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
                 const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
                 const int sp = iscan[p];
                 const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
@@ -2072,7 +2079,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
             FCU_FOR_LANES {                                      /* per mode: transform-skip decision (TEncSearch.cpp:1985-2058) */
               if (lane < 5) {
                 const int m = lane; int bestTs = 0;
-                const int mode = modeList[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : modeList[m];
+                const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
                 uint32_t dsel = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * tsv]);
                 if (tsv == 2) {
                   const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
@@ -2133,7 +2140,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
       }
       const int c = CAB_LANE0 + 5 + m;
       cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
-      g_S.vc_bits[m] = chroma_tree_bits(c, cu, m, modeList[m], g_S.lane_abs[lane]);
+      g_S.vc_bits[m] = chroma_tree_bits(c, cu, m, g_S.c_modes[m], g_S.lane_abs[lane]);
       g_S.vc_cost[m] = rd_cost(P, g_S.vc_bits[m], g_S.cm_dist[m]);
     }
   }
@@ -2153,7 +2160,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_chroma(CuObj *cu)
       }
       for (int i = lane; i < n; i += 64) {
         cu->cbf[1][i] = B->cbf[0][i]; cu->cbf[2][i] = B->cbf[1][i]; cu->tskip[1][i] = B->tskip[0][i]; cu->tskip[2][i] = B->tskip[1][i];
-        cu->intra_dir[1][i] = (uint8_t)modeList[bm];
+        cu->intra_dir[1][i] = (uint8_t)g_S.c_modes[bm];
       }
       if (lane == 0) cu->dist += g_S.cm_dist[bm];
       cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
@@ -2274,7 +2281,7 @@ FCU_DEV FCU_NOINLINE void encode_ctu(int c, const CuObj *ctu, int lastCtuOfSlice
 {
   const Env E = env_get(); c = FCU_UNI(c); ctu = FCU_UNI(ctu); lastCtuOfSlice = FCU_UNI(lastCtuOfSlice);
   const Params &P = E.C->p;
-  int stPart[4], stChild[4]; int sp = 0;
+  int *stPart = g_S.wk_part, *stChild = g_S.wk_child; int sp = 0;
   stPart[0] = 0; stChild[0] = -1;
   while (sp >= 0) {
     const int depth = sp, part = stPart[sp];
