@@ -187,7 +187,7 @@ struct alignas(16) Scratch {
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
 /* transform unit descriptor (TComTU / TComTURecurse, TLibCommon/TComTU.cpp:47-207) */
-struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c; };
+struct TU { int log2, tr_depth, part, nparts, x, y, off_y, cw, cwo, cx, cy, c_tr_depth, c_code_all, off_c, cu_depth, plast; };
 
 /* per-chain LDS */
 struct Shared {
@@ -262,11 +262,12 @@ FCU_DEV void tu_root(TU &t, int depth)
 {
   t.log2 = 6 - depth; t.tr_depth = 0; t.part = 0; t.nparts = NPART >> (2 * depth); t.x = t.y = 0; t.off_y = 0;
   t.cw = t.cwo = (CTU >> depth) >> 1; t.cx = t.cy = 0; t.c_tr_depth = 0; t.c_code_all = 1; t.off_c = 0;
+  t.cu_depth = depth; t.plast = 0;
 }
 FCU_DEV void tu_child(TU &c, const TU &p, int i, int processLast)
 {
   const int s = 1 << (p.log2 - 1);
-  c.log2 = p.log2 - 1; c.tr_depth = p.tr_depth + 1;
+  c.log2 = p.log2 - 1; c.tr_depth = p.tr_depth + 1; c.cu_depth = p.cu_depth; c.plast = processLast;
   c.nparts = p.nparts >> 2; if (c.nparts < 1) c.nparts = 1;
   c.part = p.part + i * c.nparts;
   c.x = p.x + (i & 1) * s; c.y = p.y + (i >> 1) * s; c.off_y = p.off_y + i * s * s;
@@ -279,6 +280,21 @@ FCU_DEV void tu_child(TU &c, const TU &p, int i, int processLast)
     c.cwo = pw; c.c_code_all = 0; c.c_tr_depth = p.c_tr_depth; c.cx = p.cx; c.cy = p.cy; c.off_c = p.off_c;
     c.cw = (processLast ? (i == 3) : (i == 0)) ? pw : 0;
   }
+}
+/* A TU is a function of (CU depth, transform depth, first partition, processLast of the last split): non-inlined
+ * functions receive this 13-bit key in one register and rebuild the descriptor with scalar arithmetic, instead of a
+ * 64-byte struct passed through the stack (a scratch-memory round trip per call and lane). */
+FCU_DEV uint32_t tu_key(const TU &t) { return (uint32_t)(t.cu_depth | (t.tr_depth << 2) | (t.part << 4) | (t.plast << 12)); }
+FCU_DEV TU tu_of_key(uint32_t k)
+{
+  TU t; tu_root(t, (int)(k & 3));
+  const int trd = (int)((k >> 2) & 3), part = (int)((k >> 4) & 255), pl = (int)((k >> 12) & 1);
+  for (int l = 0; l < trd; l++) {
+    TU c; int np = t.nparts >> 2; if (np < 1) np = 1;
+    tu_child(c, t, ((part - t.part) / np) & 3, pl);
+    t = c;
+  }
+  return t;
 }
 FCU_DEV int tu_part_c(const TU &t) { return t.c_code_all ? t.part : (t.part & ~3); }
 FCU_DEV int tu_nparts_c(const TU &t) { return t.c_code_all ? t.nparts : t.nparts * 4; }
@@ -1103,9 +1119,9 @@ FCU_DEV void code_intra_dir_chroma(int c, int dir)       /* TEncSbac.cpp:698-725
 FCU_DEV int chroma_final_mode(const CuObj *cu, int part) { int m = cu->intra_dir[1][part]; return m == DM_CHROMA ? cu->intra_dir[0][part & ~3] : m; }
 
 /* search-time tree walkers: xEncSubdivCbfQT / xEncCoeffQT / xGetIntraBitsQT, TEncSearch.cpp:866-1090 */
-FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, TU root, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, uint32_t root_k, int bLuma, int bChroma)
 {
-  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU root = tu_of_key(FCU_UNI(root_k)); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1131,9 +1147,9 @@ FCU_DEV FCU_NOINLINE void enc_subdiv_cbf_qt(int c, const CuObj *cu, TU root, int
   }
   (void)E;
 }
-FCU_DEV FCU_NOINLINE void enc_coeff_qt(int c, const CuObj *cu, TU root, int comp, int realCoeff)
+FCU_DEV FCU_NOINLINE void enc_coeff_qt(int c, const CuObj *cu, uint32_t root_k, int comp, int realCoeff)
 {
-  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); root = FCU_UNI(root); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU root = tu_of_key(FCU_UNI(root_k)); comp = FCU_UNI(comp); realCoeff = FCU_UNI(realCoeff);
   TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1164,23 +1180,23 @@ FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, 
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
-FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(int c, const CuObj *cu, TU tu, int bLuma, int bChroma)
+FCU_DEV FCU_NOINLINE uint32_t intra_bits_qt(int c, const CuObj *cu, uint32_t tu_k, int bLuma, int bChroma)
 {
-  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); bLuma = FCU_UNI(bLuma); bChroma = FCU_UNI(bChroma);
   cab_reset_bits(c);
   enc_intra_header(E, c, cu, tu.tr_depth, tu.part, bLuma, bChroma);
-  enc_subdiv_cbf_qt(c, cu, tu, bLuma, bChroma);
-  if (bLuma) enc_coeff_qt(c, cu, tu, 0, 0);
-  if (bChroma) { enc_coeff_qt(c, cu, tu, 1, 0); enc_coeff_qt(c, cu, tu, 2, 0); }
+  enc_subdiv_cbf_qt(c, cu, tu_key(tu), bLuma, bChroma);
+  if (bLuma) enc_coeff_qt(c, cu, tu_key(tu), 0, 0);
+  if (bChroma) { enc_coeff_qt(c, cu, tu_key(tu), 1, 0); enc_coeff_qt(c, cu, tu_key(tu), 2, 0); }
   return cab_bits(c);
 }
 
 /* xGetIntraBitsQT (luma only) for the un-split TU that tu_trial() has just coded: the same bins as
  * intra_bits_qt() on a leaf, with the PU's MPM list from the RMD (g_S.preds, same intra_dir_predictor call)
  * and the levels still in scan order in the trial buffers */
-FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, uint32_t tu_k)
 {
-  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k));
   const int part = tu.part, partSize = cu->part_size[0], log2 = tu.log2;
   cab_reset_bits(c);
   if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
@@ -1195,9 +1211,9 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, TU tu)
 }
 
 /* final-order CU syntax: encodeCoeff / xEncodeTransform, TEncEntropy.cpp:201-400 */
-FCU_DEV FCU_NOINLINE void encode_transform(int c, const CuObj *cu, int cuPart, TU root)
+FCU_DEV FCU_NOINLINE void encode_transform(int c, const CuObj *cu, int cuPart, uint32_t root_k)
 {
-  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); root = FCU_UNI(root);
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); const TU root = tu_of_key(FCU_UNI(root_k));
   TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
   while (sp >= 0) {
@@ -1240,7 +1256,7 @@ FCU_DEV void encode_cu_syntax(const Env E, int c, const CuObj *cu, int cuPart, i
   code_intra_dir_luma(c, cu, cuPart, 1);
   code_intra_dir_chroma(c, cu->intra_dir[1][cuPart]);
   TU root; tu_root(root, depth);
-  encode_transform(c, cu, cuPart, root);
+  encode_transform(c, cu, cuPart, tu_key(root));
 }
 
 /* ======================================================================================== */
@@ -1336,9 +1352,9 @@ FCU_DEV FCU_NOINLINE void copy_reco_to_pic(const Yuv *r, int x, int y, int s)
 /* generic (sequential-candidate) TU trial: xIntraCodingTUBlock, TEncSearch.cpp:1092-1387    */
 /* pixel phases use all lanes, RDOQ runs on lane 0 against coder `*cab`                       */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, TU tu, int comp, int cab, int save1load2)
+FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, int save1load2)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp); cab = FCU_UNI(cab); save1load2 = FCU_UNI(save1load2);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); comp = FCU_UNI(comp); cab = FCU_UNI(cab); save1load2 = FCU_UNI(save1load2);
   Scratch *G = E.G; const Params &P = E.C->p;
   if (comp && tu.cw == 0) { FCU_SERIAL { g_S.t_dist = 0; g_S.t_abs = 0; g_S.t_lsp = -1; } return; }
   FCU_TIC(t11_);
@@ -1433,9 +1449,9 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, TU tu, int comp, int cab, int save
 }
 
 /* xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1760-1850 */
-FCU_DEV FCU_NOINLINE void store_intra_result_qt(TU tu, int comp)
+FCU_DEV FCU_NOINLINE void store_intra_result_qt(uint32_t tu_k, int comp)
 {
-  const Env E = env_get(); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
+  const Env E = env_get(); const TU tu = tu_of_key(FCU_UNI(tu_k)); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1443,9 +1459,9 @@ FCU_DEV FCU_NOINLINE void store_intra_result_qt(TU tu, int comp)
   const uint8_t *s = yuv_plane(&G->qt_rec[layer], comp) + by * bs + bx; uint8_t *t = yuv_plane(&G->ts_rec, comp) + by * bs + bx;
   FCU_FOR_LANES { for (int i = lane; i < N * N; i += 64) { G->ts_coef[comp][i] = src[i]; t[(i / N) * bs + (i % N)] = s[(i / N) * bs + (i % N)]; } }
 }
-FCU_DEV FCU_NOINLINE void load_intra_result_qt(const CuObj *cu, TU tu, int comp)
+FCU_DEV FCU_NOINLINE void load_intra_result_qt(const CuObj *cu, uint32_t tu_k, int comp)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); comp = FCU_UNI(comp);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); comp = FCU_UNI(comp);
   Scratch *G = E.G;
   if (comp && tu.cw == 0) return;
   const int N = comp ? tu.cw : (1 << tu.log2), layer = LOG2_MAXTU - tu.log2, bs = comp ? 32 : 64, sh = comp ? 1 : 0, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y;
@@ -1460,9 +1476,9 @@ FCU_DEV FCU_NOINLINE void load_intra_result_qt(const CuObj *cu, TU tu, int comp)
 /* LEVEL = recursion level (compile-time unrolled, <= 3).  Adds to g_S.q_dist/q_cost[LEVEL].   */
 /* ======================================================================================== */
 template <int LEVEL>
-FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int reuseVc = -1)
+FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst, int reuseVc = -1)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu); checkFirst = FCU_UNI(checkFirst); reuseVc = FCU_UNI(reuseVc);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); checkFirst = FCU_UNI(checkFirst); reuseVc = FCU_UNI(reuseVc);
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = FCU_UNI((int)cu->depth_cu), part = tu.part, trDepth = tu.tr_depth, fullDepth = d + trDepth, log2 = tu.log2;
   const int partSize = FCU_UNI((int)cu->part_size[part]);
@@ -1478,23 +1494,23 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
       FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
       for (int modeId = 0; modeId < 2; modeId++) {
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)modeId; }
-        tu_trial(cu, tu, 0, (CAB_GOON), modeId == 0 ? 1 : 2);
+        tu_trial(cu, tu_key(tu), 0, (CAB_GOON), modeId == 0 ? 1 : 2);
         const uint32_t tmpDist = FCU_UNI(g_S.t_dist), tmpCbf = FCU_UNI((uint32_t)((cu->cbf[0][part] >> trDepth) & 1));
         double tmpCost;
         if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
         else {
-          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
+          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); } FCU_TOC(E, t12_, 12); }
           tmpCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], tmpDist));
         }
         if (tmpCost < singleCost) {
           singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
-          if (bestModeId == 0) { store_intra_result_qt(tu, 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
+          if (bestModeId == 0) { store_intra_result_qt(tu_key(tu), 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
         }
         if (modeId == 0) FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->tskip[0][part + i] = (uint8_t)bestModeId; }
       if (bestModeId == 0) {
-        load_intra_result_qt(cu, tu, 0);
+        load_intra_result_qt(cu, tu_key(tu), 0);
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_TEMP_BEST), lane); }
       }
     } else {
@@ -1515,10 +1531,10 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
         }
         singleDist = FCU_UNI(g_S.vc_dist[bv]); singleCbf = (uint32_t)cbf; singleCost = FCU_UNI(g_S.vc_cost[bv]);
       } else {
-        tu_trial(cu, tu, 0, (CAB_GOON), 0);
+        tu_trial(cu, tu_key(tu), 0, (CAB_GOON), 0);
         singleDist = FCU_UNI(g_S.t_dist);
         if (checkSplit) singleCbf = FCU_UNI((uint32_t)((cu->cbf[0][part] >> trDepth) & 1));
-        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu); } FCU_TOC(E, t12_, 12); }
+        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); } FCU_TOC(E, t12_, 12); }
         singleCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], singleDist));
       }
     }
@@ -1531,7 +1547,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
       uint32_t splitCbf = 0;
       for (int i = 0; i < 4; i++) {
         TU c; tu_child(c, tu, i, 0);
-        recur_luma_qt<LEVEL + 1>(cu, c, checkFirst);
+        recur_luma_qt<LEVEL + 1>(cu, tu_key(c), checkFirst);
         splitCbf |= FCU_UNI((uint32_t)((cu->cbf[0][c.part] >> c.tr_depth) & 1));
       }
       const uint32_t splitDist = FCU_UNI(g_S.q_dist[LEVEL + 1]);
@@ -1539,7 +1555,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
         cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
-      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt((CAB_GOON), cu, tu, 1, 0); } FCU_TOC(E, t12_, 12); }
+      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt((CAB_GOON), cu, tu_key(tu), 1, 0); } FCU_TOC(E, t12_, 12); }
       const double splitCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], splitDist));
       if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; } return; }
       FCU_FOR_LANES {
@@ -1556,9 +1572,9 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, TU tu, int checkFirst, int re
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
-FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(CuObj *cu, TU root, Yuv *reco)
+FCU_DEV FCU_NOINLINE void set_intra_result_luma_qt(CuObj *cu, uint32_t root_k, Yuv *reco)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); root = FCU_UNI(root); reco = FCU_UNI(reco);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU root = tu_of_key(FCU_UNI(root_k)); reco = FCU_UNI(reco);
   Scratch *G = E.G;
   TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
   st[0] = root; ci[0] = -1;
@@ -1621,9 +1637,9 @@ FCU_DEV uint32_t satd_unit(const uint8_t *org, int log2, int mode, int dc, int b
   return (uint32_t)(USZ == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
 }
 
-FCU_DEV FCU_NOINLINE void rmd(CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE void rmd(CuObj *cu, uint32_t tu_k)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k));
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2;
   build_ref(0, cu->x + tu.x, cu->y + tu.y, log2, 1);
@@ -1676,9 +1692,9 @@ FCU_DEV FCU_NOINLINE void rmd(CuObj *cu, TU tu)
 /* side by side -- pixel phases on all lanes, RDOQ + bit counting one candidate per lane.     */
 /* Restates the loop TEncSearch.cpp:2447-2516 for the bCheckFirst case (:1428-1444).          */
 /* ======================================================================================== */
-FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, TU tu)
+FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); tu = FCU_UNI(tu);
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k));
   Scratch *G = E.G; const Params &P = E.C->p;
   const int d = cu->depth_cu, N = 1 << tu.log2, log2 = tu.log2, n2 = N * N, part = tu.part;
   const int partSize = cu->part_size[part];
@@ -1832,19 +1848,19 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
   for (int pu = 0; pu < numPU; pu++) {
     TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
-    { FCU_TIC(t_); rmd(cu, tu); FCU_TOC(E, t_, 0); }
+    { FCU_TIC(t_); rmd(cu, tu_key(tu)); FCU_TOC(E, t_, 0); }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
-    if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu); FCU_TOC(E, t_, 1); }
+    if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }
     else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
       FCU_SERIAL { g_S.pu_best_cost = FCU_MAX_DOUBLE; g_S.pu_best_mode = 0; g_S.pu_best_dist = 0; }
       const int nc = g_S.n_rd;
       for (int m = 0; m < nc; m++) {
         const int orgMode = g_S.rd_mode[m];
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
-        recur_luma_qt<0>(cu, tu, 1);
+        recur_luma_qt<0>(cu, tu_key(tu), 1);
         if (g_S.q_cost[0] < g_S.pu_best_cost) {
           FCU_SERIAL { g_S.pu_best_mode = orgMode; g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
-          set_intra_result_luma_qt(cu, tu, recoT);
+          set_intra_result_luma_qt(cu, tu_key(tu), recoT);
           FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
         }
       }
@@ -1855,10 +1871,10 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
     if (log2 > min_tu_log2_in_cu(d, partSize)) {
       const int orgMode = g_S.pu_best_mode;
       FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) cu->intra_dir[0][partOffset + i] = (uint8_t)orgMode; cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane); if (lane == 0) { g_S.q_dist[0] = 0; g_S.q_cost[0] = 0; } }
-      { FCU_TIC(t_); recur_luma_qt<0>(cu, tu, 0, singleTU ? g_S.pu_best_vc : -1); FCU_TOC(E, t_, 4); }
+      { FCU_TIC(t_); recur_luma_qt<0>(cu, tu_key(tu), 0, singleTU ? g_S.pu_best_vc : -1); FCU_TOC(E, t_, 4); }
       if (g_S.q_cost[0] < g_S.pu_best_cost) {
         FCU_SERIAL { g_S.pu_best_dist = g_S.q_dist[0]; g_S.pu_best_cost = g_S.q_cost[0]; }
-        set_intra_result_luma_qt(cu, tu, recoT);
+        set_intra_result_luma_qt(cu, tu_key(tu), recoT);
         FCU_FOR_LANES { for (int i = lane; i < tu.nparts; i += 64) { G->tmp_tr_idx[i] = cu->tr_idx[partOffset + i]; G->tmp_cbf[i] = cu->cbf[0][partOffset + i]; G->tmp_tskip[i] = cu->tskip[0][partOffset + i]; } }
       }
     }
