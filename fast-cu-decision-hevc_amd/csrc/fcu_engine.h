@@ -1956,7 +1956,8 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(int c, const CuObj *cu, int m, in
   const ChromaModeBuf *B = &E.G->cm[m];
   cab_reset_bits(c);
   code_intra_dir_chroma(c, mode);
-  TU st[4]; int ci[4];
+  /* the five lanes (modes) walk the same luma TU tree in lockstep: they share the LDS walker stack (same values) */
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci;
   for (int pass = 0; pass < 3; pass++) {                      /* 0: subdiv/cbf walk, 1: Cb coefficients, 2: Cr coefficients */
     int sp = 0; tu_root(st[0], cu->depth_cu); ci[0] = -1;
     while (sp >= 0) {
