@@ -109,6 +109,32 @@ def test_full_4k_frame_as_slice_chains(pkg):
     eng.destroy()
 
 
+@pytest.mark.parametrize("qp", [22, 37])
+def test_4k_slices_at_other_qps(pkg, qp):
+    """The first six CTU rows of the 4K frame as six slice chains at the other ends of the QP range."""
+    w, h, sl, rows = 3840, 2160, 60, 6
+    Y, U, V = pkg.synth.textured(w, h, seed=8)
+    eng = pkg.CuEngine(w, h, max_chains=rows)
+    rec, out = eng.init_chain(0, (Y, U, V), qp, slice_ctus=sl)
+    planes = eng._keep[0][0]
+    eng.set_range(0, 0, sl)
+    for k in range(1, rows):
+        eng.init_chain(k, planes, qp, slice_ctus=sl, rec=rec, out=out)
+        eng.set_range(k, k * sl, sl)
+    eng.compress_chains(0, rows, sl)
+    eng.sync()
+    ref = hmo_py.Encoder(Y, U, V, qp, slice_ctus=sl)
+    raw = out.cpu().numpy()
+    nbytes = pkg.engine.CTU_OUT_BYTES
+    for a in range(rows * sl):
+        ref.compress_ctu(a)
+        got = pkg.engine.ctu_to_dict(pkg.engine.CtuOut.from_buffer_copy(raw[a * nbytes:(a + 1) * nbytes].tobytes()))
+        _compare_ctu(got, ref.ctu_arrays(a), f"4K qp{qp} ctu{a}")
+    for p, q in zip([t.cpu().numpy() for t in rec], ref.rec):
+        assert np.array_equal(p[:rows * 64 >> (0 if p.shape[1] == w else 1)], q[:rows * 64 >> (0 if q.shape[1] == w else 1)])
+    eng.destroy()
+
+
 def test_chain_range_must_follow_slices(pkg):
     w, h = 256, 128
     Y, U, V = pkg.synth.mixed(w, h, seed=3)
