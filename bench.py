@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--ctus-per-step", type=int, default=1)
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--state", choices=["training", "testing"], default="training",
+                    help="fork state of the timed steps.  training (default, the headline metric): exhaustive RDO.  "
+                         "testing: the fork's Naive pruning; the OBF maps come from the device pre-pass, the first warm-up "
+                         "step runs in the Verifying state and its counters set the per-depth switches (SetDecisionSwitch)")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +127,20 @@ def main():
     def step():
         eng.compress_chains(0, n_chains, args.ctus_per_step)
 
-    for _ in range(args.warmup):
+    switches = None
+    if args.state == "testing":
+        # untimed: OBF pre-pass of every frame, one Verifying step, switches from its counters, then Testing
+        assert args.warmup >= 1, "--state testing uses the first warm-up step as the Verifying step"
+        obf = [eng.obf_prepass(fr[0])[0][0].contiguous() for fr in frames]
+        chain_obf = [obf[ci // len(qps)] for ci in range(n_chains)]     # chains_for_rank: frame-major, QP-minor
+        for ci in range(n_chains):
+            eng.set_decision(ci, pkg.engine.VERIFYING, chain_obf[ci])
+        step()
+        ver = eng.verify_counts(0, n_chains)
+        switches = pkg.engine.decision_switch(ver)
+        for ci in range(n_chains):
+            eng.set_decision(ci, pkg.engine.TESTING, chain_obf[ci], *switches)
+    for _ in range(args.warmup - (1 if args.state == "testing" else 0)):
         step()
     eng.sync()
     eng.kernel_ms()                       # drop warm-up launches from the event accumulator
@@ -153,9 +170,12 @@ def main():
             "config": {"workload": f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO "
                                    f"(BASELINE configs[2]); {args.frames} frames x {len(qps)} QPs = {n_chains} chains/GPU, "
                                    f"{args.ctus_per_step} CTU/chain/step",
-                       "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world},
+                       "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world,
+                       "state": args.state if switches is None else
+                       f"testing (Naive switches skip2Nx2N={switches[0].tolist()} terminate={switches[1].tolist()} from a Verifying step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(n_chains, args.ctus_per_step),
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": measured_traffic(n_chains, args.ctus_per_step) if switches is None else None,
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches},
         }
         if not args.no_cpu_baseline:

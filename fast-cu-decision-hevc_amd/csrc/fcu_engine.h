@@ -150,7 +150,13 @@ struct Chain {
   Cabac state;                 /* m_pppcRDSbacCoder[0][CI_CURR_BEST] between CTUs */
   unsigned long long n_tu_trials;
   unsigned long long prof[16];
+  /* fork decision state (tools_YS.cpp): frame state, per-depth switches of the Naive model, OBF count map, g_iVerResult */
+  int dec_state, depth_exception, obf_stride;
+  uint8_t sw_skip[4], sw_term[4];
+  const int16_t *obf;
+  double ver[4][6];
 };
+enum { DEC_TRAINING = 0, DEC_VERIFYING = 1, DEC_TESTING = 2 };
 
 /* per-depth working CU (TComDataCU best/temp objects, TEncCu.cpp:163-198) */
 struct CuObj {
@@ -230,6 +236,7 @@ struct Shared {
   /* explicit stacks of the serial tree walkers (a private array indexed by the stack pointer would live in scratch memory) */
   TU wk_st[4]; int wk_ci[4]; int wk_part[4], wk_child[4];
   double cand_cost[12];                             /* RMD candidate costs (CandCostList, TEncSearch.cpp:2289) */
+  double dec_j0, dec_j1; int dec_cnt, dec_flip;     /* fork hooks: J0 / J1 / Num_OBF / bPartition_True of the CU being closed */
 };
 
 enum { CAB_GOON = 0, CAB_CUR0 = 1, CAB_LANE0 = 1 + (MAXDEPTH + 1) };
@@ -2233,6 +2240,28 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(int d, int partSize)
   check_best_mode(d);
 }
 
+/* fork hooks of xCompressCU for its default control (YSGlobalControl, tools_YS.cpp:4-58: Naive model on N_OBF).
+ * Num_OBF = 4x4 blocks of the CU with a positive OBF count (TEncCu.cpp:585-600); the Naive label is Skip2Nx2N when
+ * there is one, TerminateCU when there is none (tools_YS.cpp:686-695, TEncCu.cpp:670-678). */
+FCU_DEV FCU_NOINLINE int cu_num_obf(int x, int y, int s)
+{
+  const Env E = env_get(); x = FCU_UNI(x); y = FCU_UNI(y); s = FCU_UNI(s);
+  FCU_SERIAL g_S.dec_cnt = 0;
+  FCU_FOR_LANES {
+    const int q = s >> 2; int n = 0;
+    for (int i = lane; i < q * q; i += 64) n += E.C->obf[((y >> 2) + i / q) * E.C->obf_stride + (x >> 2) + i % q] > 0;
+    if (n) FCU_ATOMIC_ADD(&g_S.dec_cnt, n);
+  }
+  return FCU_UNI(g_S.dec_cnt);
+}
+/* countTFPN + countRDLoss (tools_YS.cpp:968-986; ResultType order TP,FP,TN,FN,FPLoss,FNLoss, globals_YS.h:81-89) */
+FCU_DEV void count_verify(Chain *C, int d, int predictSkip, int partitionTrue, double j0, double j1)
+{
+  const double loss = fabs(j0 - j1);
+  if (predictSkip) { C->ver[d][partitionTrue ? 0 : 1] += 1.0; if (!partitionTrue) C->ver[d][4] += loss; }
+  else { C->ver[d][partitionTrue ? 3 : 2] += 1.0; if (partitionTrue) C->ver[d][5] += loss; }
+}
+
 template <int D>
 FCU_DEV FCU_NOINLINE void compress_cu()
 {
@@ -2241,6 +2270,17 @@ FCU_DEV FCU_NOINLINE void compress_cu()
   const CuObj *b0 = cu_best(E, D);
   const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
   const int boundary = !((x + s - 1 < P.width) && (y + s - 1 < P.height));
+  const int state = E.C->dec_state;
+  int skip2Nx2N = 0, earlyTerminate = 0, predictSkip = 0;
+  if (!boundary && state != DEC_TRAINING) {
+    const int nobf = cu_num_obf(x, y, s);
+    predictSkip = nobf > 0;
+    if (state == DEC_TESTING) {                              /* TEncCu.cpp:951-996 */
+      if (E.C->sw_term[D]) earlyTerminate = !predictSkip;
+      if (E.C->sw_skip[D]) skip2Nx2N = predictSkip;
+      if (D == 3 && nobf > 0 && E.C->depth_exception) skip2Nx2N = earlyTerminate = 0;
+    }
+  }
   if (!boundary) {
     FCU_FOR_LANES {                                          /* source block -> L2-resident CU buffer */
       for (int i = lane; i < s * s; i += 64) G->org[D].y[(i / s) * 64 + (i % s)] = E.C->org[0][(y + i / s) * E.C->stride[0] + x + (i % s)];
@@ -2251,9 +2291,14 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       }
     }
     cu_init(cu_temp(E, D), D, x, y, zidx);
-    check_rd_cost_intra(D, SIZE_2Nx2N);
+    if (!skip2Nx2N) check_rd_cost_intra(D, SIZE_2Nx2N);      /* :1040; skipped => the best cost stays MAX_DOUBLE (:1077) */
     cu_init(cu_temp(E, D), D, x, y, zidx);
-    if (D == MAXDEPTH) { check_rd_cost_intra(D, SIZE_NxN); cu_init(cu_temp(E, D), D, x, y, zidx); }
+    if (D == MAXDEPTH && !earlyTerminate) {                  /* :1141-1143 */
+      FCU_SERIAL { g_S.dec_j0 = cu_best(E, D)->cost; g_S.dec_flip = g_S.best_idx[D]; }
+      check_rd_cost_intra(D, SIZE_NxN);
+      FCU_SERIAL { g_S.dec_flip ^= g_S.best_idx[D]; g_S.dec_j1 = g_S.dec_flip ? cu_best(E, D)->cost : cu_temp(E, D)->cost; }   /* :1175-1183 */
+      cu_init(cu_temp(E, D), D, x, y, zidx);
+    }
     FCU_SERIAL {
       CuObj *best = cu_best(E, D);
       if (best->cost != FCU_MAX_DOUBLE) {                   /* fork: TEncCu.cpp:1224 */
@@ -2266,6 +2311,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
   }
   cu_init(cu_temp(E, D), D, x, y, zidx);
   if constexpr (D < MAXDEPTH) {
+   if (!earlyTerminate) {                                    /* bSubBranch = false, TEncCu.cpp:1257-1260 */
     const int nd = D + 1, hs = s >> 1, qn = NPART >> (2 * nd);
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
@@ -2292,9 +2338,16 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       CuObj *t = cu_temp(E, D);
       if (!boundary) { cab_reset_bits((CAB_GOON)); code_split_flag(E, (CAB_GOON), t, 0, D); t->bits += cab_bits((CAB_GOON)); t->bins += g_S.cab[CAB_GOON].bins; }
       t->cost = rd_cost(P, t->bits, t->dist);
+      if (skip2Nx2N) cu_best(E, D)->cost = FCU_MAX_DOUBLE;   /* :1446-1449 */
+      g_S.dec_j0 = cu_best(E, D)->cost; g_S.dec_j1 = t->cost; g_S.dec_flip = g_S.best_idx[D];   /* J0, J1 :1450-1451 */
     }
     FCU_FOR_LANES cab_copy(slot_ptr(E, D, CI_TEMP_BEST), slot_ptr(E, nd, CI_NEXT_BEST), lane);
     check_best_mode(D);
+    FCU_SERIAL g_S.dec_flip ^= g_S.best_idx[D];              /* bPartition_True = xCheckBestMode(...) */
+   }
+  }
+  if (!boundary && state == DEC_VERIFYING) {                 /* TEncCu.cpp:1489-1497 */
+    FCU_SERIAL count_verify(E.C, D, predictSkip, g_S.dec_flip, g_S.dec_j0, g_S.dec_j1);
   }
   cu_copy_to_pic(cu_best(E, D));
   copy_reco_to_pic(&G->reco[D][g_S.reco_best_idx[D]], x, y, s);

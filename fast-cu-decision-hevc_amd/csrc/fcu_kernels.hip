@@ -210,6 +210,54 @@ int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bit
   return FCU_OK;
 }
 
+int fcu_chain_set_decision(fcu_ctx *c, int chain, const fcu_decision_params *dp)
+{
+  if (!c || !dp || chain < 0 || chain >= c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_chain_set_decision: bad argument");
+  if (dp->state < FCU_TRAINING || dp->state > FCU_TESTING) return fail(FCU_ERR_ARG, "fcu_chain_set_decision: unknown state");
+  if (dp->state != FCU_TRAINING && !dp->dev_obf) return fail(FCU_ERR_ARG, "fcu_chain_set_decision: Verifying / Testing need the frame's OBF map (fcu_obf_prepass)");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_decision: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  h.dec_state = dp->state; h.depth_exception = dp->depth_exception != 0; h.obf = dp->dev_obf; h.obf_stride = c->sp.width / 4;
+  for (int d = 0; d < 4; d++) { h.sw_skip[d] = dp->sw_skip2nx2n[d] != 0; h.sw_term[d] = dp->sw_terminate[d] != 0; }
+  memset(h.ver, 0, sizeof(h.ver));
+  /* only the decision block of the descriptor: the chain's position and context state on the device stay as they are */
+  const size_t off = offsetof(Chain, dec_state);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + off, (const char *)&h + off, sizeof(Chain) - off, hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+int fcu_get_verify_counts(fcu_ctx *c, int first, int n, fcu_verify_counts *host_sum)
+{
+  if (!c || !host_sum || first < 0 || n <= 0 || first + n > c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_get_verify_counts: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<Chain> h((size_t)n);
+  HIPCHK(hipMemcpy(h.data(), &c->d_chains[first], sizeof(Chain) * (size_t)n, hipMemcpyDeviceToHost));
+  memset(host_sum, 0, sizeof(*host_sum));
+  for (int i = 0; i < n; i++) for (int d = 0; d < 4; d++) for (int k = 0; k < 6; k++) host_sum->n[d][k] += h[(size_t)i].ver[d][k];
+  return FCU_OK;
+}
+
+void fcu_decision_switch(const fcu_verify_counts *v, const double th_skip[4], const double th_term[4], uint8_t sw_skip[4], uint8_t sw_term[4])
+{
+  for (int d = 0; d < 4; d++) {
+    const double tp = v->n[d][0], fp = v->n[d][1], tn = v->n[d][2], fn = v->n[d][3];
+    const double ths = (th_skip && th_skip[d] != 0) ? th_skip[d] : 0.8, tht = (th_term && th_term[d] != 0) ? th_term[d] : 0.8;
+    const double ps = (tp + fp == 0) ? 0.0 : tp / (tp + fp);            /* getSkipPrecision, tools_YS.cpp:1251-1258 */
+    const double pt = (tn + fn == 0) ? 0.0 : tn / (tn + fn);            /* getTermPrecision, :1259-1266 */
+    sw_skip[d] = ps > ths; sw_term[d] = pt > tht;
+  }
+}
+
+int fcu_frame_state(int poc, int period, int n_training, int n_verifying)
+{
+  if (period <= 0) return FCU_TRAINING;
+  const int r = poc % period;
+  return r < n_training ? FCU_TRAINING : (r < n_training + n_verifying ? FCU_VERIFYING : FCU_TESTING);
+}
+
 /* diagnostic: resident workgroups (= chains) per CU the runtime grants the engine kernel */
 int fcu_chains_per_cu(void)
 {

@@ -47,9 +47,23 @@ class CtuOut(C.Structure):
 
 CTU_OUT_BYTES = C.sizeof(CtuOut)
 
+TRAINING, VERIFYING, TESTING = 0, 1, 2          # CurrentState (getCurrentState, tools_YS.cpp:1237-1242)
+
+
+class DecisionParams(C.Structure):
+    """fcu_decision_params (include/fcu.h): frame state, Naive switches per depth, the frame's OBF map."""
+    _fields_ = [("state", C.c_int), ("depth_exception", C.c_int), ("sw_skip2nx2n", C.c_uint8 * 4),
+                ("sw_terminate", C.c_uint8 * 4), ("dev_obf", C.c_void_p)]
+
+
+class VerifyCounts(C.Structure):
+    """fcu_verify_counts: g_iVerResult[depth][TP, FP, TN, FN, FPLoss, FNLoss]."""
+    _fields_ = [("n", (C.c_double * 6) * 4)]
+
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
-           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu"]
+           "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
+           "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state"]
 
 
 def lib_path():
@@ -86,8 +100,33 @@ def load_lib():
     lib.fcu_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.fcu_debug_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.fcu_last_error.restype = C.c_char_p
+    lib.fcu_chain_set_decision.argtypes = [C.c_void_p, C.c_int, C.POINTER(DecisionParams)]
+    lib.fcu_get_verify_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VerifyCounts)]
+    lib.fcu_decision_switch.restype = None
+    lib.fcu_decision_switch.argtypes = [C.POINTER(VerifyCounts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_frame_state.argtypes = [C.c_int] * 4
     _lib = lib
     return lib
+
+
+def decision_switch(ver, th_skip=(0, 0, 0, 0), th_term=(0, 0, 0, 0)):
+    """SetDecisionSwitch (tools_YS.cpp:1123-1154) on summed verification counters [4, 6]: (sw_skip[4], sw_term[4]).
+    Host arithmetic of libfcu.so; needs no GPU."""
+    lib = load_lib()
+    v = VerifyCounts()
+    a = np.ascontiguousarray(ver, np.float64).reshape(4, 6)
+    for d in range(4):
+        for k in range(6):
+            v.n[d][k] = a[d, k]
+    ts, tt = np.ascontiguousarray(th_skip, np.float64), np.ascontiguousarray(th_term, np.float64)
+    sk, te = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
+    lib.fcu_decision_switch(C.byref(v), ts.ctypes.data, tt.ctypes.data, sk.ctypes.data, te.ctypes.data)
+    return sk, te
+
+
+def frame_state(poc, period=60, n_training=2, n_verifying=1):
+    """getCurrentState (tools_YS.cpp:1237-1242) with the reference's defaults g_iP / g_iT / g_iV (tools_YS.cpp:41-43)."""
+    return load_lib().fcu_frame_state(poc, period, n_training, n_verifying)
 
 
 def ctu_to_dict(c):
@@ -226,6 +265,25 @@ class CuEngine:
         ms = (C.c_float * 2)()
         self._chk(self.lib.fcu_obf_prepass(self.h, n, t.data_ptr(), obf.data_ptr(), yc.ctypes.data, ms, None), "fcu_obf_prepass")
         return obf, yc, (ms[0], ms[1])
+
+    # -- fork decision hooks of xCompressCU
+    def set_decision(self, chain, state, obf=None, sw_skip=(0, 0, 0, 0), sw_term=(0, 0, 0, 0), depth_exception=0):
+        """obf: this frame's map from obf_prepass (int16 tensor [height/4, width/4] on this device)."""
+        dp = DecisionParams()
+        dp.state, dp.depth_exception = state, depth_exception
+        for d in range(4):
+            dp.sw_skip2nx2n[d], dp.sw_terminate[d] = int(sw_skip[d]), int(sw_term[d])
+        if obf is not None:
+            assert obf.is_contiguous() and obf.dtype == self.torch.int16 and tuple(obf.shape) == (self.height // 4, self.width // 4)
+            dp.dev_obf = obf.data_ptr()
+            self._keep_obf = getattr(self, "_keep_obf", {})
+            self._keep_obf[chain] = obf
+        self._chk(self.lib.fcu_chain_set_decision(self.h, chain, C.byref(dp)), "fcu_chain_set_decision")
+
+    def verify_counts(self, first, n=1):
+        v = VerifyCounts()
+        self._chk(self.lib.fcu_get_verify_counts(self.h, first, n, C.byref(v)), "fcu_get_verify_counts")
+        return np.array([[v.n[d][k] for k in range(6)] for d in range(4)], np.float64)
 
     # -- TEncCu::destroy
     def destroy(self):

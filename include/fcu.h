@@ -16,6 +16,10 @@
  *     (TEncCu.cpp:359, TEncSlice.cpp:1468-1487)
  *   TEncSlice::getOutlierWithDCT (fork pre-pass)   fcu_obf_prepass
  *     (TEncSlice.cpp:878-1173, TEncGOP.cpp:1096)
+ *   fork decision hooks of TEncCu::xCompressCU     fcu_chain_set_decision (frame state + Naive switches + OBF map),
+ *     (TEncCu.cpp:504-507,585-603,951-996,           fcu_get_verify_counts (g_iVerResult of the Verifying frame),
+ *      1040,1143,1257,1446,1489-1497;                fcu_decision_switch (SetDecisionSwitch), fcu_frame_state
+ *      tools_YS.cpp:686-695,968-986,1123-1154,1237)   (getCurrentState)
  *   m_pppcRDSbacCoder[0][CI_CURR_BEST] state      fcu_get_ctx_state
  *     (TEncSlice.cpp:1417,1477)
  *
@@ -109,6 +113,33 @@ int  fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17);
  * the histogram and the counting kernel.  Synchronous (the threshold fit runs on the host between the kernels). */
 int  fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc,
                      float *kernel_ms2, void *hip_stream);
+/* ---- the fork's fast CU-size decision (its default control: Naive model on the N_OBF feature, YSGlobalControl,
+ * tools_YS.cpp:4-58).  A chain starts in FCU_TRAINING (exhaustive RDO).  FCU_VERIFYING is exhaustive too and counts,
+ * per depth, how the Naive label ("split" when the CU holds an outlier block, "do not split" when it holds none)
+ * compares with the RDO outcome.  FCU_TESTING prunes: at a depth whose sw_skip2nx2n is on, a CU labelled "split" skips
+ * its 2Nx2N check; at a depth whose sw_terminate is on, a CU labelled "do not split" is not divided further (at depth 3:
+ * NxN is not tried).  dev_obf is the frame's map from fcu_obf_prepass ((height/4) x (width/4) int16). */
+enum { FCU_TRAINING = 0, FCU_VERIFYING = 1, FCU_TESTING = 2 };      /* CurrentState, getCurrentState tools_YS.cpp:1237 */
+typedef struct fcu_decision_params {
+  int state;
+  int depth_exception;           /* g_bDepthException (tools_YS.cpp:25): no pruning of depth-3 CUs that hold outliers */
+  uint8_t sw_skip2nx2n[4];       /* g_bDecisionSwitch[depth][Naive][Skip2Nx2N]   */
+  uint8_t sw_terminate[4];       /* g_bDecisionSwitch[depth][Naive][TerminateCU] */
+  const int16_t *dev_obf;
+} fcu_decision_params;
+/* g_iVerResult[depth][Naive][TP, FP, TN, FN, FPLoss, FNLoss] (globals_YS.h:81-89) */
+typedef struct fcu_verify_counts { double n[4][6]; } fcu_verify_counts;
+/* Set the decision state of a bound chain (any time between launches) and clear its verification counters. */
+int  fcu_chain_set_decision(fcu_ctx *c, int chain, const fcu_decision_params *dp);
+/* Sum of the verification counters of chains [first, first+n), added up in chain order.  Synchronous. */
+int  fcu_get_verify_counts(fcu_ctx *c, int first, int n, fcu_verify_counts *host_sum);
+/* SetDecisionSwitch (tools_YS.cpp:1123-1154): a switch turns on when the precision of its label on the Verifying frame
+ * exceeds the threshold (0 => the reference's default 0.8).  Pure host arithmetic. */
+void fcu_decision_switch(const fcu_verify_counts *v, const double th_skip[4], const double th_term[4],
+                         uint8_t sw_skip2nx2n[4], uint8_t sw_terminate[4]);
+/* getCurrentState (tools_YS.cpp:1237-1242) for picture `poc` with g_iP = period, g_iT = n_training, g_iV = n_verifying
+ * (reference defaults 60 / 2 / 1, tools_YS.cpp:41-43) */
+int  fcu_frame_state(int poc, int period, int n_training, int n_verifying);
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);
 const char *fcu_last_error(void);

@@ -3,8 +3,8 @@
  *
  * Plain-C CPU restatement of the HM-16.3 all-intra CU depth/mode RDO decision loop
  * (TEncCu::compressCtu + TEncCu::encodeCtu context replay) as found in
- * Jiraiya812/Fast-CU-Decision-HEVC, with the fork's state fixed to "Training"
- * (exhaustive HM RDO).
+ * Jiraiya812/Fast-CU-Decision-HEVC.  Default state "Training" (exhaustive HM RDO, SURVEY.md section 5 / 7.4
+ * item 11); hmo_set_decision selects the fork's Verifying / Testing states with its default Naive model.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
  * code.  The HIP product path never links or calls it.
@@ -131,6 +131,14 @@ const HmoCabac *hmo_get_cabac(const HmoEnc *e);
 void    hmo_compress_frame(HmoEnc *e);
 int     hmo_num_ctus(const HmoEnc *e);
 uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int ctuRsAddr);
+
+/* fork states (CurrentState, globals_YS.h; getCurrentState, tools_YS.cpp:1237-1242) */
+#define HMO_TRAINING  0
+#define HMO_VERIFYING 1
+#define HMO_TESTING   2
+void    hmo_set_decision(HmoEnc *e, int state, const uint8_t *sw_skip, const uint8_t *sw_term, int depth_exception, const int16_t *obf);
+void    hmo_get_verify(const HmoEnc *e, double *out24);
+void    hmo_decision_switch(const double *ver24, const double *th_skip, const double *th_term, uint8_t *sw_skip, uint8_t *sw_term);
 
 /* ---- leaf functions exported for known-answer tests -------------------------------- */
 void    hmo_fwd_transform(const int16_t *resi, int stride, int32_t *coef, int log2, int useDst);

@@ -88,6 +88,11 @@ struct HmoEnc {
   double  rq_cost_coeff[1024], rq_cost_sig[1024], rq_cost_coeff0[1024];
   int     rq_rate_up[1024], rq_rate_down[1024], rq_sig_delta[1024];
   int32_t rq_delta_u[1024];
+  /* fork decision state (tools_YS.cpp) */
+  int dec_state, depth_exception, obf_stride;
+  uint8_t sw_skip[4], sw_term[4];
+  const int16_t *obf;
+  double ver[4][6];                  /* g_iVerResult[depth][Naive][ResultType] */
   /* statistics for tests */
   uint64_t n_tu_trials, n_rmd;
 };

@@ -6,6 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NPART = 256
+TRAINING, VERIFYING, TESTING = 0, 1, 2      # fork states (getCurrentState, tools_YS.cpp:1237)
 
 
 class Params(C.Structure):
@@ -50,6 +51,9 @@ def load():
     lib.hmo_tcm_threshold.restype = C.c_double
     lib.hmo_tcm_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.hmo_ctu_replay_bits.argtypes = [C.c_void_p, C.c_int]
+    lib.hmo_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.hmo_get_verify.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hmo_decision_switch.argtypes = [C.c_void_p] * 5
     return lib
 
 
@@ -92,6 +96,20 @@ class Encoder:
         c = self.lib.hmo_get_cabac(self.h).contents
         return np.ctypeslib.as_array(c.ctx).copy(), int(c.frac)
 
+    def set_decision(self, state, obf=None, sw_skip=(0, 0, 0, 0), sw_term=(0, 0, 0, 0), depth_exception=0):
+        """Fork state of the frame + Naive decision switches per depth + the frame's OBF map (int16 [h/4, w/4])."""
+        self._obf = None if obf is None else np.ascontiguousarray(obf, dtype=np.int16)
+        assert state == TRAINING or self._obf is not None
+        sk, te = np.ascontiguousarray(sw_skip, np.uint8), np.ascontiguousarray(sw_term, np.uint8)
+        self.lib.hmo_set_decision(self.h, state, sk.ctypes.data, te.ctypes.data, depth_exception,
+                                  None if self._obf is None else self._obf.ctypes.data)
+
+    def verify_counts(self):
+        """g_iVerResult[depth][TP, FP, TN, FN, FPLoss, FNLoss] since set_decision."""
+        v = np.zeros((4, 6), np.float64)
+        self.lib.hmo_get_verify(self.h, v.ctypes.data)
+        return v
+
     def replay_bits(self, a):
         return self.lib.hmo_ctu_replay_bits(self.h, a)
 
@@ -117,3 +135,13 @@ def obf_prepass(Y):
     err = lib.hmo_obf_prepass(Y.ctypes.data, w, h, w, obf.ctypes.data, yc.ctypes.data)
     assert err == 0, "amplitude beyond the reference's bucket array"
     return obf, yc
+
+
+def decision_switch(ver, th_skip=(0, 0, 0, 0), th_term=(0, 0, 0, 0)):
+    """SetDecisionSwitch: (sw_skip[4], sw_term[4]) from the Verifying frame's counters."""
+    lib = load()
+    v = np.ascontiguousarray(ver, np.float64)
+    a, b = np.ascontiguousarray(th_skip, np.float64), np.ascontiguousarray(th_term, np.float64)
+    sk, te = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
+    lib.hmo_decision_switch(v.ctypes.data, a.ctypes.data, b.ctypes.data, sk.ctypes.data, te.ctypes.data)
+    return sk, te

@@ -734,7 +734,7 @@ static int check_best_mode(HmoEnc *e, int d)
   }
   return 0;
 }
-static void check_rd_cost_intra(HmoEnc *e, int d, int partSize)
+static int check_rd_cost_intra(HmoEnc *e, int d, int partSize)
 {
   HmoCU *cu = e->temp[d];
   const int n = cu->nparts, s = cu_size(cu);
@@ -749,7 +749,7 @@ static void check_rd_cost_intra(HmoEnc *e, int d, int partSize)
   cu->bits = hmo_bits(e);
   cu->bins = e->goon_bins;
   cu->cost = calc_rd_cost(e, cu->bits, cu->dist);
-  check_best_mode(e, d);
+  return check_best_mode(e, d);
 }
 
 static void copy_reco_to_pic(HmoEnc *e, const HmoYuv *r, int x, int y, int s)
@@ -766,13 +766,47 @@ static void copy_reco_to_pic(HmoEnc *e, const HmoYuv *r, int x, int y, int s)
 }
 
 /* ------------------------------------------------------------------------------------
- * xCompressCU, TEncCu.cpp:460-1616 (fork state = Training: no early decisions)
+ * fork decision hooks of xCompressCU with the fork's default control (YSGlobalControl, tools_YS.cpp:4-58):
+ * main model Naive on the N_OBF feature, no assistant / multi-model / depth exception unless asked for.
+ * ---------------------------------------------------------------------------------- */
+/* Num_OBF of a CU: 4x4 blocks of its area whose OBF count is positive (TEncCu.cpp:585-600) */
+static int cu_num_obf(const HmoEnc *e, int x, int y, int s)
+{
+  int n = 0;
+  for (int yy = 0; yy < s / 4; yy++)
+    for (int xx = 0; xx < s / 4; xx++) n += e->obf[(y / 4 + yy) * e->obf_stride + x / 4 + xx] > 0;
+  return n;
+}
+/* countTFPN + countRDLoss, tools_YS.cpp:968-986 (ResultType order TP,FP,TN,FN,FPLoss,FNLoss, globals_YS.h:81-89) */
+static void count_verify(HmoEnc *e, int d, int skipPredicted, int partitionTrue, double j0, double j1)
+{
+  const double loss = fabs(j0 - j1);
+  if (skipPredicted) { e->ver[d][partitionTrue ? 0 : 1] += 1.0; if (!partitionTrue) e->ver[d][4] += loss; }
+  else { e->ver[d][partitionTrue ? 3 : 2] += 1.0; if (partitionTrue) e->ver[d][5] += loss; }
+}
+
+/* ------------------------------------------------------------------------------------
+ * xCompressCU, TEncCu.cpp:460-1616.  Training: exhaustive; Verifying: exhaustive + TP/FP/TN/FN bookkeeping
+ * (:1489-1497); Testing: Skip2Nx2N / TerminateCU pruning where the depth's switch is on (:951-996,1040,1143,1257,1446).
  * ---------------------------------------------------------------------------------- */
 static void compress_cu(HmoEnc *e, int d)
 {
   HmoCU *bestInit = e->best[d];
   const int x = bestInit->x, y = bestInit->y, zidx = bestInit->zidx, s = HMO_CTU >> d;
   const int boundary = !((x + s - 1 < e->p.width) && (y + s - 1 < e->p.height));
+  int skip2Nx2N = 0, earlyTerminate = 0, predictSkip = 0, partitionTrue = 0;
+  double j0 = HMO_MAX_DOUBLE, j1 = 0;
+  if (!boundary && e->dec_state != HMO_TRAINING) {
+    /* Naive model: label +1 (Skip2Nx2N) when the CU holds an outlier block, -1 (TerminateCU) when it holds none
+     * (DoPrediction, tools_YS.cpp:686-695; TEncCu.cpp:670-678).  Testing predicts only where a switch is on (:660). */
+    const int nobf = cu_num_obf(e, x, y, s);
+    predictSkip = nobf > 0;
+    if (e->dec_state == HMO_TESTING) {
+      if (e->sw_term[d]) earlyTerminate = !predictSkip;                                  /* :967-970 */
+      if (e->sw_skip[d]) skip2Nx2N = predictSkip;                                        /* :971-974 */
+      if (d == 3 && nobf > 0 && e->depth_exception) skip2Nx2N = earlyTerminate = 0;      /* :991-995 */
+    }
+  }
   if (!boundary) {
     for (int yy = 0; yy < s; yy++) memcpy(e->org_yuv[d]->y + yy * 64, e->org[0] + (y + yy) * e->stride[0] + x, (size_t)s);
     for (int yy = 0; yy < s / 2; yy++) {
@@ -780,10 +814,12 @@ static void compress_cu(HmoEnc *e, int d)
       memcpy(e->org_yuv[d]->v + yy * 32, e->org[2] + (y / 2 + yy) * e->stride[2] + x / 2, (size_t)(s / 2));
     }
     cu_init(e->temp[d], d, x, y, zidx);
-    check_rd_cost_intra(e, d, HMO_SIZE_2Nx2N);
+    if (!skip2Nx2N) check_rd_cost_intra(e, d, HMO_SIZE_2Nx2N);  /* :1040; skipped => best cost stays MAX_DOUBLE (:1077) */
+    j0 = e->best[d]->cost;                                      /* :1072,1078 */
     cu_init(e->temp[d], d, x, y, zidx);
-    if (d == HMO_MAXDEPTH) {
-      check_rd_cost_intra(e, d, HMO_SIZE_NxN);
+    if (d == HMO_MAXDEPTH && !earlyTerminate) {                 /* :1141-1143 */
+      partitionTrue = check_rd_cost_intra(e, d, HMO_SIZE_NxN);
+      j1 = partitionTrue ? e->best[d]->cost : e->temp[d]->cost; /* :1175-1183 */
       cu_init(e->temp[d], d, x, y, zidx);
     }
     if (e->best[d]->cost != HMO_MAX_DOUBLE) {               /* fork: TEncCu.cpp:1224 */
@@ -793,9 +829,10 @@ static void compress_cu(HmoEnc *e, int d)
       e->best[d]->bins += e->goon_bins;
       e->best[d]->cost = calc_rd_cost(e, e->best[d]->bits, e->best[d]->dist);
     }
+    if (d < HMO_MAXDEPTH) j0 = e->best[d]->cost;                /* :1233-1235 */
   }
   cu_init(e->temp[d], d, x, y, zidx);
-  if (d < HMO_MAXDEPTH) {
+  if (d < HMO_MAXDEPTH && !earlyTerminate) {                    /* bSubBranch = false, :1257-1260 */
     const int nd = d + 1, hs = s >> 1, qn = (HMO_NPART >> (2 * nd));
     for (int i = 0; i < 4; i++) {
       int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
@@ -825,8 +862,11 @@ static void compress_cu(HmoEnc *e, int d)
     }
     e->temp[d]->cost = calc_rd_cost(e, e->temp[d]->bits, e->temp[d]->dist);
     e->slot[d][CI_TEMP_BEST] = e->slot[nd][CI_NEXT_BEST];
-    check_best_mode(e, d);
+    if (skip2Nx2N) e->best[d]->cost = HMO_MAX_DOUBLE;           /* :1446-1449 */
+    j0 = e->best[d]->cost; j1 = e->temp[d]->cost;               /* :1450-1451 */
+    partitionTrue = check_best_mode(e, d);
   }
+  if (!boundary && e->dec_state == HMO_VERIFYING) count_verify(e, d, predictSkip, partitionTrue, j0, j1);   /* :1489-1497 */
   cu_copy_to_pic(e, e->best[d]);
   copy_reco_to_pic(e, e->reco_best[d], x, y, s);
 }
@@ -913,6 +953,29 @@ void hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const u
   e->stride[0] = e->p.width; e->stride[1] = e->stride[2] = e->p.width / 2;
 }
 int hmo_num_ctus(const HmoEnc *e) { return e->n_ctu; }
+/* fork state of the frame (getCurrentState, tools_YS.cpp:1237-1242), the per-depth decision switches of the Naive model
+ * (g_bDecisionSwitch[depth][Naive][Skip2Nx2N / TerminateCU]) and the frame's OBF count map ((height/4) x (width/4));
+ * clears the verification counters. */
+void hmo_set_decision(HmoEnc *e, int state, const uint8_t *sw_skip, const uint8_t *sw_term, int depth_exception, const int16_t *obf)
+{
+  e->dec_state = state; e->depth_exception = depth_exception; e->obf = obf; e->obf_stride = e->p.width / 4;
+  for (int d = 0; d < 4; d++) { e->sw_skip[d] = sw_skip ? sw_skip[d] : 0; e->sw_term[d] = sw_term ? sw_term[d] : 0; }
+  memset(e->ver, 0, sizeof(e->ver));
+}
+/* g_iVerResult[depth][Naive][TP,FP,TN,FN,FPLoss,FNLoss] accumulated over the CTUs compressed since hmo_set_decision */
+void hmo_get_verify(const HmoEnc *e, double *out24) { memcpy(out24, e->ver, sizeof(e->ver)); }
+/* SetDecisionSwitch, tools_YS.cpp:1123-1154 with getSkipPrecision / getTermPrecision (:1251-1266):
+ * a depth's switch turns on when the precision measured on the Verifying frame exceeds its threshold
+ * (0 => g_dPrecision_Th_Default = 0.8, tools_YS.cpp:46). */
+void hmo_decision_switch(const double *ver24, const double *th_skip, const double *th_term, uint8_t *sw_skip, uint8_t *sw_term)
+{
+  for (int d = 0; d < 4; d++) {
+    const double tp = ver24[d * 6 + 0], fp = ver24[d * 6 + 1], tn = ver24[d * 6 + 2], fn = ver24[d * 6 + 3];
+    const double ths = (th_skip && th_skip[d] != 0) ? th_skip[d] : 0.8, tht = (th_term && th_term[d] != 0) ? th_term[d] : 0.8;
+    const double ps = (tp + fp == 0) ? 0 : tp / (tp + fp), pt = (tn + fn == 0) ? 0 : tn / (tn + fn);
+    sw_skip[d] = ps > ths; sw_term[d] = pt > tht;
+  }
+}
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 const HmoCabac *hmo_get_cabac(const HmoEnc *e) { return &e->slot[0][CI_CURR_BEST]; }
 uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int a) { return e->replay_bits[a]; }

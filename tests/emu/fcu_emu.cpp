@@ -34,6 +34,14 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, int tools, c
 void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); delete e; }
 void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, a); e->c.next_ctu = a + 1; }
 void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX); *frac = e->c.state.frac; }
+void fcu_emu_set_decision(void *h, int state, const uint8_t *sw_skip, const uint8_t *sw_term, int depth_exception, const int16_t *obf)
+{
+  Chain &c = ((EmuChain *)h)->c;
+  c.dec_state = state; c.depth_exception = depth_exception; c.obf = obf; c.obf_stride = c.p.width / 4;
+  for (int d = 0; d < 4; d++) { c.sw_skip[d] = sw_skip[d]; c.sw_term[d] = sw_term[d]; }
+  memset(c.ver, 0, sizeof(c.ver));
+}
+void fcu_emu_get_verify(void *h, double *out24) { memcpy(out24, ((EmuChain *)h)->c.ver, sizeof(double) * 24); }
 unsigned long long fcu_emu_tu_trials(void *h) { return ((EmuChain *)h)->c.n_tu_trials; }
 int fcu_emu_sizes(int which) { return which == 0 ? (int)sizeof(Scratch) : which == 1 ? (int)sizeof(Shared) : (int)sizeof(Chain); }
 }

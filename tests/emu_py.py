@@ -16,6 +16,8 @@ def load():
     lib.fcu_emu_destroy.argtypes = [C.c_void_p]
     lib.fcu_emu_compress_ctu.argtypes = [C.c_void_p, C.c_int]
     lib.fcu_emu_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_emu_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fcu_emu_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.fcu_emu_tu_trials.restype = C.c_ulonglong
     lib.fcu_emu_tu_trials.argtypes = [C.c_void_p]
     return lib
@@ -34,6 +36,17 @@ class EmuEncoder:
 
     def compress_ctu(self, a):
         self.lib.fcu_emu_compress_ctu(self.h, a)
+
+    def set_decision(self, state, obf=None, sw_skip=(0, 0, 0, 0), sw_term=(0, 0, 0, 0), depth_exception=0):
+        self._obf = None if obf is None else np.ascontiguousarray(obf, dtype=np.int16)
+        sk, te = np.ascontiguousarray(sw_skip, np.uint8), np.ascontiguousarray(sw_term, np.uint8)
+        self.lib.fcu_emu_set_decision(self.h, state, sk.ctypes.data, te.ctypes.data, depth_exception,
+                                      None if self._obf is None else self._obf.ctypes.data)
+
+    def verify_counts(self):
+        v = np.zeros((4, 6), np.float64)
+        self.lib.fcu_emu_get_verify(self.h, v.ctypes.data)
+        return v
 
     def compress_frame(self):
         for a in range(self.n_ctu):

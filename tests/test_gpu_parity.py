@@ -165,3 +165,101 @@ def test_tool_flags_through_the_abi(pkg, ts, tsf, sbh, strong):
     ctx_o, frac_o = ref.cabac()
     assert np.array_equal(ctx_e, ctx_o) and frac_e == frac_o
     eng.destroy()
+
+
+# ---- the fork's fast CU-size decision (Verifying / Testing states, Naive model on the OBF map) ----------------------
+def _decide_frame(pkg, eng, yuv, qp, state, obf_dev, sw=((0, 0, 0, 0), (0, 0, 0, 0)), dex=0):
+    eng.init_chain(0, yuv, qp=qp)
+    eng.set_decision(0, state, obf_dev, *sw, depth_exception=dex)
+    eng.compress_chains(0, 1, eng.n_ctu)
+    eng.sync()
+    return [eng.ctu_out(0, a) for a in range(eng.n_ctu)]
+
+
+@pytest.mark.parametrize("gen,w,h,qp", [("smooth", 192, 128, 32), ("mixed", 136, 72, 27)])
+def test_decision_states_match_oracle(pkg, gen, w, h, qp):
+    """OBF map from the device pre-pass -> Verifying frame (counters) -> switches -> Testing frames: every state of
+    the fork's xCompressCU hooks bit-exact against the oracle, through the C ABI."""
+    eng_mod = pkg.engine
+    Y, U, V = getattr(pkg.synth, gen)(w, h, seed=5)
+    obf_o, _ = hmo_py.obf_prepass(Y)
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    if w % 64 == 0 and h % 64 == 0:
+        obf_t, _, _ = eng.obf_prepass(Y)                  # the map the engine itself produces
+        obf_dev = obf_t[0].contiguous()
+        assert np.array_equal(obf_dev.cpu().numpy(), obf_o)
+    else:
+        import torch
+        obf_dev = torch.as_tensor(obf_o).cuda()
+
+    def check(state, sw=((0, 0, 0, 0), (0, 0, 0, 0)), dex=0):
+        got = _decide_frame(pkg, eng, (Y, U, V), qp, state, obf_dev, sw, dex)
+        ref = hmo_py.Encoder(Y, U, V, qp)
+        ref.set_decision(state, obf_o, *sw, depth_exception=dex)
+        ref.compress_frame()
+        for a in range(eng.n_ctu):
+            _compare_ctu(got[a], ref.ctu_arrays(a), f"{gen} state{state} sw{sw} ctu{a}")
+        for p, q in zip(eng.rec_planes(0), ref.rec):
+            assert np.array_equal(p, q)
+        ctx_e, frac_e = eng.ctx_state(0)
+        ctx_o, frac_o = ref.cabac()
+        assert np.array_equal(ctx_e, ctx_o) and frac_e == frac_o
+        return ref
+
+    ref = check(eng_mod.VERIFYING)
+    ver = eng.verify_counts(0)
+    assert np.array_equal(ver, ref.verify_counts())       # TP/FP/TN/FN and the f64 RD-loss sums
+    sw = eng_mod.decision_switch(ver)
+    check(eng_mod.TESTING, sw)
+    check(eng_mod.TESTING, ((1, 1, 1, 1), (1, 1, 1, 1)))
+    check(eng_mod.TESTING, ((0, 1, 0, 1), (1, 0, 1, 0)), dex=1)
+    check(eng_mod.TRAINING)                               # back to exhaustive on the same chain
+    eng.destroy()
+
+
+def test_decision_needs_the_obf_map(pkg):
+    Y, U, V = pkg.synth.smooth(128, 64, seed=5)
+    eng = pkg.CuEngine(128, 64, max_chains=1)
+    with pytest.raises(pkg.FcuError):
+        eng.set_decision(0, pkg.engine.TESTING, None)     # chain not bound
+    eng.init_chain(0, (Y, U, V), qp=32)
+    with pytest.raises(pkg.FcuError):
+        eng.set_decision(0, pkg.engine.TESTING, None)     # Testing without a map
+    eng.destroy()
+
+
+def test_4k_testing_state_obeys_the_rule(pkg):
+    """Full-size property: six CTU rows of the 4K frame in the Testing state with every switch on, OBF map from the
+    device pre-pass.  The published quadtrees must follow the Naive rule everywhere, the pruned search must be
+    cheaper in TU trials than the exhaustive one, and a sample of CTUs is compared with the oracle."""
+    from test_decision import check_rule
+    w, h, sl, rows, qp = 3840, 2160, 60, 6, 32
+    Y, U, V = pkg.synth.textured(w, h, seed=7)
+    eng = pkg.CuEngine(w, h, max_chains=rows)
+    obf_t, _, _ = eng.obf_prepass(Y)
+    obf_dev = obf_t[0].contiguous()
+    obf = obf_dev.cpu().numpy()
+    sw = ((1, 1, 1, 1), (1, 1, 1, 1))
+    trials = {}
+    for state in (pkg.engine.TRAINING, pkg.engine.TESTING):
+        rec, out = eng.init_chain(0, (Y, U, V), qp, slice_ctus=sl)
+        planes = eng._keep[0][0]
+        for k in range(rows):
+            if k:
+                eng.init_chain(k, planes, qp, slice_ctus=sl, rec=rec, out=out)
+            eng.set_range(k, k * sl, sl)
+            eng.set_decision(k, state, obf_dev, *sw)
+        eng.compress_chains(0, rows, sl)
+        eng.sync()
+        trials[state] = sum(eng.debug_counters(k)[16] for k in range(rows))
+    raw = out.cpu().numpy()
+    nbytes = pkg.engine.CTU_OUT_BYTES
+    got = [pkg.engine.ctu_to_dict(pkg.engine.CtuOut.from_buffer_copy(raw[a * nbytes:(a + 1) * nbytes].tobytes())) for a in range(rows * sl)]
+    assert check_rule(got, obf, w, h, *sw) >= rows * sl
+    assert trials[pkg.engine.TESTING] < trials[pkg.engine.TRAINING]
+    ref = hmo_py.Encoder(Y, U, V, qp, slice_ctus=sl)
+    ref.set_decision(hmo_py.TESTING, obf, *sw)
+    for a in range(sl + 5):                               # first slice and the start of the second
+        ref.compress_ctu(a)
+        _compare_ctu(got[a], ref.ctu_arrays(a), f"4K testing ctu{a}")
+    eng.destroy()
