@@ -132,6 +132,12 @@ void    hmo_compress_frame(HmoEnc *e);
 int     hmo_num_ctus(const HmoEnc *e);
 uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int ctuRsAddr);
 
+/* in-loop deblocking of the decided picture (TComLoopFilter::loopFilterPic, TComLoopFilter.cpp:130; TEncGOP.cpp:1160),
+ * in place on the reconstruction planes */
+void    hmo_deblock(HmoEnc *e, int betaOffsetDiv2, int tcOffsetDiv2);
+void    hmo_deblock_pic(const HmoCtu *pic, int width, int height, uint8_t *recY, uint8_t *recU, uint8_t *recV,
+                        int betaOffsetDiv2, int tcOffsetDiv2);
+
 /* fork states (CurrentState, globals_YS.h; getCurrentState, tools_YS.cpp:1237-1242) */
 #define HMO_TRAINING  0
 #define HMO_VERIFYING 1

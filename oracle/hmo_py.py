@@ -51,6 +51,8 @@ def load():
     lib.hmo_tcm_threshold.restype = C.c_double
     lib.hmo_tcm_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.hmo_ctu_replay_bits.argtypes = [C.c_void_p, C.c_int]
+    lib.hmo_deblock.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hmo_deblock_pic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.hmo_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.hmo_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.hmo_decision_switch.argtypes = [C.c_void_p] * 5
@@ -110,6 +112,10 @@ class Encoder:
         self.lib.hmo_get_verify(self.h, v.ctypes.data)
         return v
 
+    def deblock(self, beta_offset_div2=0, tc_offset_div2=0):
+        """In-loop deblocking of the decided picture, in place on self.rec (TComLoopFilter::loopFilterPic)."""
+        self.lib.hmo_deblock(self.h, beta_offset_div2, tc_offset_div2)
+
     def replay_bits(self, a):
         return self.lib.hmo_ctu_replay_bits(self.h, a)
 
@@ -145,3 +151,16 @@ def decision_switch(ver, th_skip=(0, 0, 0, 0), th_term=(0, 0, 0, 0)):
     sk, te = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
     lib.hmo_decision_switch(v.ctypes.data, a.ctypes.data, b.ctypes.data, sk.ctypes.data, te.ctypes.data)
     return sk, te
+
+
+def deblock_pic(ctus, width, height, rec, beta_offset_div2=0, tc_offset_div2=0):
+    """Deblocks (Y, U, V) uint8 planes in place given the picture's per-CTU decisions: `ctus` is a ctypes array of
+    Ctu (or anything with the same memory layout, e.g. the engine's fcu_ctu_out array as bytes)."""
+    lib = load()
+    buf = np.frombuffer(ctus, dtype=np.uint8) if not isinstance(ctus, np.ndarray) else ctus
+    assert buf.nbytes == C.sizeof(Ctu) * ((width + 63) // 64) * ((height + 63) // 64)
+    buf = np.ascontiguousarray(buf)
+    for a in rec:
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    lib.hmo_deblock_pic(buf.ctypes.data, width, height, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data,
+                        beta_offset_div2, tc_offset_div2)

@@ -38,6 +38,7 @@
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComRdCost.h"
 #include "TLibCommon/TComBitCounter.h"
+#include "TLibCommon/TComLoopFilter.h"
 #include "TLibEncoder/TEncSbac.h"
 #include "TLibEncoder/TEncEntropy.h"
 #include "TLibEncoder/TEncBinCoderCABACCounter.h"
@@ -178,6 +179,28 @@ void ref_set_ctu_field(int ctu, int field, const unsigned char *v)
       case 9: case 10: case 11: c->getCbf(ComponentID(field - 9))[i] = v[i]; break;
     }
   }
+}
+
+void ref_set_ctu_qp(int ctu, const signed char *qp) { TComDataCU *c = g_pic->getCtu(ctu); for (int i = 0; i < 256; i++) c->getQP()[i] = qp[i]; }
+void ref_get_rec(int comp, unsigned char *plane)
+{
+  TComPicYuv *r = g_pic->getPicYuvRec(); const ComponentID c = ComponentID(comp);
+  const Pel *p = r->getAddr(c); const int s = r->getStride(c), w = r->getWidth(c), h = r->getHeight(c);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) plane[y * w + x] = (unsigned char)p[y * s + x];
+}
+/* the reference's in-loop deblocking of the whole picture (TComLoopFilter::loopFilterPic, called at TEncGOP.cpp:1160
+ * with the configuration TEncGOP.cpp:1155-1159 / TEncSlice.cpp:446-470 applies by default: filter enabled, beta / tc
+ * offsets 0, LFCrossSliceBoundaryFlag 1, LFCrossTileBoundaryFlag 1) */
+void ref_deblock(int betaOffsetDiv2, int tcOffsetDiv2)
+{
+  g_slice->setDeblockingFilterDisable(false);
+  g_slice->setDeblockingFilterBetaOffsetDiv2(betaOffsetDiv2); g_slice->setDeblockingFilterTcOffsetDiv2(tcOffsetDiv2);
+  g_slice->setLFCrossSliceBoundaryFlag(true);
+  TComLoopFilter lf;
+  lf.create(g_uiMaxCUDepth);
+  lf.setCfg(true);
+  lf.loopFilterPic(g_pic);
+  lf.destroy();
 }
 
 /* descend a TU tree: root = the CU at (zidx, depth) of CTU `ctu`; path[k] = child index at level k */

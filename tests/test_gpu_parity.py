@@ -135,6 +135,50 @@ def test_4k_slices_at_other_qps(pkg, qp):
     eng.destroy()
 
 
+def test_baseline_config0_416x240(pkg):
+    """BASELINE configs[0]: one 416x240 frame (the plumbing frame of SURVEY.md 8d), QP 32, one slice -- whole frame,
+    partial CTUs on the right (416 = 6.5 CTUs) and at the bottom (240 = 3.75 CTUs)."""
+    w, h, qp = 416, 240, 32
+    Y, U, V = pkg.synth.smooth(w, h)
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    eng.init_chain(0, (Y, U, V), qp=qp)
+    eng.compress_chains(0, 1, eng.n_ctu)
+    eng.sync()
+    ref = hmo_py.Encoder(Y, U, V, qp)
+    ref.compress_frame()
+    assert eng.n_ctu == 28
+    for a in range(eng.n_ctu):
+        _compare_ctu(eng.ctu_out(0, a), ref.ctu_arrays(a), f"416x240 ctu{a}")
+    for p, q in zip(eng.rec_planes(0), ref.rec):
+        assert np.array_equal(p, q)
+    ctx_e, frac_e = eng.ctx_state(0)
+    ctx_o, frac_o = ref.cabac()
+    assert np.array_equal(ctx_e, ctx_o) and frac_e == frac_o
+    eng.destroy()
+
+
+def test_baseline_config1_1080p(pkg):
+    """BASELINE configs[1] size: one 1920x1080 frame, QP 32, one CTU row per slice = 17 chains (the last row is
+    partial: 1080 = 16.875 CTUs), all 510 CTUs against the oracle."""
+    w, h, qp, sl = 1920, 1080, 32, 30
+    Y, U, V = pkg.synth.textured(w, h, seed=9)
+    eng = pkg.CuEngine(w, h, max_chains=17)
+    n_sl, rec, out = eng.init_slice_chains(0, (Y, U, V), qp, sl)
+    assert n_sl == 17 and eng.n_ctu == 510
+    eng.compress_chains(0, n_sl, sl)
+    eng.sync()
+    ref = hmo_py.Encoder(Y, U, V, qp, slice_ctus=sl)
+    ref.compress_frame()
+    raw = out.cpu().numpy()
+    nbytes = pkg.engine.CTU_OUT_BYTES
+    for a in range(eng.n_ctu):
+        got = pkg.engine.ctu_to_dict(pkg.engine.CtuOut.from_buffer_copy(raw[a * nbytes:(a + 1) * nbytes].tobytes()))
+        _compare_ctu(got, ref.ctu_arrays(a), f"1080p ctu{a}")
+    for p, q in zip([t.cpu().numpy() for t in rec], ref.rec):
+        assert np.array_equal(p, q)
+    eng.destroy()
+
+
 def test_chain_range_must_follow_slices(pkg):
     w, h = 256, 128
     Y, U, V = pkg.synth.mixed(w, h, seed=3)
