@@ -16,6 +16,7 @@
 #include <vector>
 #include "fcu_host.h"
 #include "fcu_obf.h"
+#include "fcu_deblock.h"
 
 using namespace fcu;
 
@@ -317,6 +318,32 @@ int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev
   if (host_yc) memcpy(host_yc, yc.data(), yc.size() * sizeof(double));
   for (int i = 0; i < 4; i++) hipEventDestroy(e[i]);
   hipFree(d_hist); hipFree(d_thr);
+  return FCU_OK;
+}
+
+int fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
+                int beta_offset_div2, int tc_offset_div2, float *kernel_ms2, void *hip_stream)
+{
+  if (!c || !dev_out || !dev_rec_y || !dev_rec_u || !dev_rec_v) return fail(FCU_ERR_ARG, "fcu_deblock: bad argument");
+  if (beta_offset_div2 < -6 || beta_offset_div2 > 6 || tc_offset_div2 < -6 || tc_offset_div2 > 6) return fail(FCU_ERR_ARG, "fcu_deblock: offsets are limited to [-6, 6]");
+  HIPCHK(hipSetDevice(c->sp.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int w = c->sp.width, h = c->sp.height, w_ctu = (w + 63) / 64;
+  const unsigned n0 = (unsigned)((w >> 3) * (h >> 2)), n1 = (unsigned)((w >> 2) * (h >> 3));
+  hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+  if (kernel_ms2) { for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&e[i])); HIPCHK(hipEventRecord(e[0], st)); }
+  /* all vertical edges of the picture before the first horizontal one (TComLoopFilter.cpp:133-154): stream order */
+  hipLaunchKernelGGL(dbk_pass<0>, dim3((n0 + DBK_THREADS - 1) / DBK_THREADS), dim3(DBK_THREADS), 0, st, dev_out, dev_rec_y, dev_rec_u, dev_rec_v, w, h, w_ctu, beta_offset_div2, tc_offset_div2);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms2) HIPCHK(hipEventRecord(e[1], st));
+  hipLaunchKernelGGL(dbk_pass<1>, dim3((n1 + DBK_THREADS - 1) / DBK_THREADS), dim3(DBK_THREADS), 0, st, dev_out, dev_rec_y, dev_rec_u, dev_rec_v, w, h, w_ctu, beta_offset_div2, tc_offset_div2);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms2) {
+    HIPCHK(hipEventRecord(e[2], st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipEventElapsedTime(&kernel_ms2[0], e[0], e[1]); hipEventElapsedTime(&kernel_ms2[1], e[1], e[2]);
+    for (int i = 0; i < 3; i++) hipEventDestroy(e[i]);
+  }
   return FCU_OK;
 }
 

@@ -63,7 +63,7 @@ class VerifyCounts(C.Structure):
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
-           "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state"]
+           "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock"]
 
 
 def lib_path():
@@ -105,6 +105,7 @@ def load_lib():
     lib.fcu_decision_switch.restype = None
     lib.fcu_decision_switch.argtypes = [C.POINTER(VerifyCounts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcu_frame_state.argtypes = [C.c_int] * 4
+    lib.fcu_deblock.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
     _lib = lib
     return lib
 
@@ -284,6 +285,20 @@ class CuEngine:
         v = VerifyCounts()
         self._chk(self.lib.fcu_get_verify_counts(self.h, first, n, C.byref(v)), "fcu_get_verify_counts")
         return np.array([[v.n[d][k] for k in range(6)] for d in range(4)], np.float64)
+
+    # -- TComLoopFilter::loopFilterPic
+    def deblock(self, chain=None, beta_offset_div2=0, tc_offset_div2=0, timed=False, stream=None, out=None, rec=None):
+        """Deblocks, in place, the reconstruction planes bound to `chain` (all slice chains of a picture share them)
+        once every CTU of the picture has been decided -- or explicit device tensors: `out` = the picture's
+        fcu_ctu_out array as uint8, `rec` = (Y, U, V).  Returns (ms vertical pass, ms horizontal pass) if timed."""
+        if chain is not None:
+            _, rec, out = self._keep[chain]
+        assert out.numel() >= self.n_ctu * CTU_OUT_BYTES and rec[0].numel() == self.width * self.height
+        ms = (C.c_float * 2)() if timed else None
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._chk(self.lib.fcu_deblock(self.h, out.data_ptr(), rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr(),
+                                       beta_offset_div2, tc_offset_div2, ms, s), "fcu_deblock")
+        return (ms[0], ms[1]) if timed else None
 
     # -- TEncCu::destroy
     def destroy(self):

@@ -20,6 +20,8 @@
  *     (TEncCu.cpp:504-507,585-603,951-996,           fcu_get_verify_counts (g_iVerResult of the Verifying frame),
  *      1040,1143,1257,1446,1489-1497;                fcu_decision_switch (SetDecisionSwitch), fcu_frame_state
  *      tools_YS.cpp:686-695,968-986,1123-1154,1237)   (getCurrentState)
+ *   TComLoopFilter::loopFilterPic                  fcu_deblock (in-loop deblocking of the decided picture)
+ *     (TComLoopFilter.cpp:130, TEncGOP.cpp:1160)
  *   m_pppcRDSbacCoder[0][CI_CURR_BEST] state      fcu_get_ctx_state
  *     (TEncSlice.cpp:1417,1477)
  *
@@ -140,6 +142,14 @@ void fcu_decision_switch(const fcu_verify_counts *v, const double th_skip[4], co
 /* getCurrentState (tools_YS.cpp:1237-1242) for picture `poc` with g_iP = period, g_iT = n_training, g_iV = n_verifying
  * (reference defaults 60 / 2 / 1, tools_YS.cpp:41-43) */
 int  fcu_frame_state(int poc, int period, int n_training, int n_verifying);
+/* In-loop deblocking of a completely decided all-intra picture, in place on its reconstruction planes:
+ * TComLoopFilter::loopFilterPic (TComLoopFilter.cpp:130-155) as TEncGOP::compressGOP runs it after the last slice of the
+ * picture (TEncGOP.cpp:1155-1160), with the encoder's default control -- filter enabled, LFCrossSliceBoundaryFlag 1,
+ * LFCrossTileBoundaryFlag 1 (TAppEncCfg.cpp:813-818,848-849) -- and the slice's beta / tc offsets (div 2, -6..6).
+ * dev_out is the picture's fcu_ctu_out array (depth, part_size, tr_idx and qp are read).  Two kernels on `hip_stream`;
+ * asynchronous unless kernel_ms2 is given, which then receives the durations of the vertical- and horizontal-edge pass. */
+int  fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
+                 int beta_offset_div2, int tc_offset_div2, float *kernel_ms2, void *hip_stream);
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);
 const char *fcu_last_error(void);

@@ -87,8 +87,8 @@ static int calc_dq(const uint8_t *p, int o) { return iabs(p[0] - 2 * p[o] + p[2 
  * the segment's first line, o: step across the edge, step: step along it */
 static void luma_segment(uint8_t *p, int o, int step, int qp, int betaOff, int tcOff)
 {
-  const int tc = k_tc[clip3(0, 53, qp + 2 * (2 - 1) + (tcOff << 1))];       /* Bs = 2, DEFAULT_INTRA_TC_OFFSET = 2 */
-  const int beta = k_beta[clip3(0, 51, qp + (betaOff << 1))];
+  const int tc = k_tc[clip3(0, 53, qp + 2 * (2 - 1) + tcOff * 2)];       /* Bs = 2, DEFAULT_INTRA_TC_OFFSET = 2 */
+  const int beta = k_beta[clip3(0, 51, qp + betaOff * 2)];
   const int side = (beta + (beta >> 1)) >> 3, thrCut = tc * 10;
   const int dp0 = calc_dp(p, o), dq0 = calc_dq(p, o), dp3 = calc_dp(p + 3 * step, o), dq3 = calc_dq(p + 3 * step, o);
   const int d0 = dp0 + dq0, d3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
@@ -102,7 +102,7 @@ static void luma_segment(uint8_t *p, int o, int step, int qp, int betaOff, int t
 static void pel_filter_chroma(uint8_t *p, int o, int tc)
 {
   const int m4 = p[0], m3 = p[-o], m5 = p[o], m2 = p[-2 * o];
-  const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+  const int delta = clip3(-tc, tc, ((((m4 - m3) * 4) + m2 - m5 + 4) >> 3));
   p[-o] = (uint8_t)clip3(0, 255, m3 + delta);
   p[0]  = (uint8_t)clip3(0, 255, m4 - delta);
 }
@@ -129,7 +129,7 @@ void hmo_deblock_pic(const HmoCtu *pic, int width, int height, uint8_t *recY, ui
         if ((pos4 & 3) == 0) {                                         /* chroma: 8-sample chroma grid, :216-221,700-707 */
           int qc = qp;                                                 /* cb / cr QP offsets 0 */
           if (qc >= 58) qc -= 6; else if (qc >= 0) qc = k_chroma_scale[qc];       /* :747-761 */
-          const int tc = k_tc[clip3(0, 53, qc + 2 * (2 - 1) + (tcOffsetDiv2 << 1))];
+          const int tc = k_tc[clip3(0, 53, qc + 2 * (2 - 1) + tcOffsetDiv2 * 2)];
           for (int c = 0; c < 2; c++) {
             uint8_t *q = chroma[c] + (y4 * 2) * cw + x4 * 2;
             for (int i = 0; i < 2; i++) {

@@ -60,3 +60,20 @@ def test_encoder_deblock_is_the_picture_function(built, pkg):
     # nothing further than 3 samples from an 8-sample grid line can change
     diff = np.argwhere(e.rec[0] != before[0])
     assert all(min(x % 8, 8 - x % 8) <= 3 or min(y % 8, 8 - y % 8) <= 3 for y, x in diff)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
+def test_kernel_source_on_cpu_matches_reference(built, path):
+    """csrc/fcu_deblock.h compiled for the CPU (tests/emu/dbk_emu.cpp: grid as a loop) against the reference's output:
+    the GPU-less check of the kernels' indexing and arithmetic."""
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "emu", "libdbk_emu.so"))
+    lib.dbk_emu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
+    g = np.load(path)
+    w, h = int(g["width"]), int(g["height"])
+    rec = [np.ascontiguousarray(g["rec_" + c]).copy() for c in "yuv"]
+    arr = ctus_from_golden(g)
+    lib.dbk_emu(C.addressof(arr), rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, w, h,
+                int(g["beta_offset_div2"]), int(g["tc_offset_div2"]))
+    for k, c in enumerate("yuv"):
+        want = g["out_" + c]
+        assert np.array_equal(rec[k], want), f"plane {c}: {np.argwhere(rec[k] != want)[:4].tolist()}"

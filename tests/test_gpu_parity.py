@@ -307,3 +307,47 @@ def test_4k_testing_state_obeys_the_rule(pkg):
         ref.compress_ctu(a)
         _compare_ctu(got[a], ref.ctu_arrays(a), f"4K testing ctu{a}")
     eng.destroy()
+
+
+# ---- in-loop deblocking (TComLoopFilter::loopFilterPic) -------------------------------------------------------------
+def test_deblock_matches_reference_golden(pkg):
+    """fcu_deblock on the inputs of tests/golden/deblock_*.npz against the planes the reference's own TComLoopFilter
+    produced for them (generator: oracle/ref/make_golden_deblock.py): pinned parity, through the C ABI."""
+    import glob
+    import os
+    import torch
+    from test_deblock import ctus_from_golden
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "deblock_*.npz")))
+    assert len(paths) == 6
+    for path in paths:
+        g = np.load(path)
+        w, h = int(g["width"]), int(g["height"])
+        eng = pkg.CuEngine(w, h, max_chains=1)
+        out = torch.frombuffer(bytearray(bytes(ctus_from_golden(g))), dtype=torch.uint8).cuda()
+        rec = [torch.as_tensor(np.ascontiguousarray(g["rec_" + c])).cuda() for c in "yuv"]
+        eng.deblock(out=out, rec=rec, beta_offset_div2=int(g["beta_offset_div2"]), tc_offset_div2=int(g["tc_offset_div2"]))
+        eng.sync()
+        for k, c in enumerate("yuv"):
+            got, want = rec[k].cpu().numpy(), g["out_" + c]
+            assert np.array_equal(got, want), f"{os.path.basename(path)} plane {c}: {np.argwhere(got != want)[:4].tolist()}"
+        eng.destroy()
+
+
+def test_decide_then_deblock_1080p(pkg):
+    """The picture pipeline of TEncGOP::compressGOP for an intra picture: all slices decided (17 slice chains), then
+    the loop filter over the whole picture -- planes against the oracle doing the same on the CPU."""
+    w, h, qp, sl = 1920, 1080, 32, 30
+    Y, U, V = pkg.synth.textured(w, h, seed=9)
+    eng = pkg.CuEngine(w, h, max_chains=17)
+    n_sl, rec, out = eng.init_slice_chains(0, (Y, U, V), qp, sl)
+    eng.compress_chains(0, n_sl, sl)
+    ms = eng.deblock(0, timed=True)                        # same stream order: after the decisions
+    ref = hmo_py.Encoder(Y, U, V, qp, slice_ctus=sl)
+    ref.compress_frame()
+    before = ref.rec[0].copy()
+    ref.deblock()
+    assert not np.array_equal(before, ref.rec[0])
+    for p, q in zip([t.cpu().numpy() for t in rec], ref.rec):
+        assert np.array_equal(p, q)
+    assert ms[0] > 0 and ms[1] > 0
+    eng.destroy()
