@@ -81,6 +81,15 @@ __device__ static inline void dbk_line_chroma(int c[4], int tc)
   c[2] = dbk_clip3(0, 255, c[2] - delta);
 }
 
+/* z-order index of the 4x4 partition (x4, y4) inside its CTU: the bits of x and y interleaved, x in the even positions
+ * (g_auiRasterToZscan, initZscanToRaster TComRom.cpp) -- computed instead of looked up, which saves a dependent gather */
+__device__ static inline int dbk_zidx(int x4, int y4)
+{
+  int x = x4 & 15, y = y4 & 15;
+  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55;
+  y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
+  return x | (y << 1);
+}
 struct DbkPart { int flag, qp; };
 /* CU data of the partition (x4, y4) (4-sample units of the picture) for direction DIR: is its left / top border a
  * filtered edge, and its QP */
@@ -88,7 +97,7 @@ template <int DIR>
 __device__ static inline DbkPart dbk_part(const fcu_ctu_out *out, int w_ctu, int x4, int y4)
 {
   const fcu_ctu_out *c = &out[(y4 >> 4) * w_ctu + (x4 >> 4)];
-  const int z = k_r2z[(y4 & 15) * 16 + (x4 & 15)];
+  const int z = dbk_zidx(x4, y4);
   DbkPart r;
   r.qp = c->qp[z];
   const int pos = (DIR == 0 ? x4 : y4) * 4;
@@ -98,7 +107,7 @@ __device__ static inline DbkPart dbk_part(const fcu_ctu_out *out, int w_ctu, int
 }
 __device__ static inline int dbk_qp_of(const fcu_ctu_out *out, int w_ctu, int x4, int y4)
 {
-  return out[(y4 >> 4) * w_ctu + (x4 >> 4)].qp[k_r2z[(y4 & 15) * 16 + (x4 & 15)]];
+  return out[(y4 >> 4) * w_ctu + (x4 >> 4)].qp[dbk_zidx(x4, y4)];
 }
 
 template <int DIR>
@@ -112,7 +121,7 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
     if (y4 >= (h >> 2)) return;
     const int x4 = x8 * 2;
     const DbkPart q = dbk_part<0>(out, w_ctu, x4, y4);
-    if (!q.flag) return;
+    if (!q.flag) return;                                       /* includes the picture border x = 0 (:358-365) */
     const int qp = (dbk_qp_of(out, w_ctu, x4 - 1, y4) + q.qp + 1) >> 1;
     int m[4][8];
     uint8_t *p = Y + (size_t)(y4 * 4) * w + x4 * 4 - 4;
@@ -147,16 +156,20 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
     const int ns = w >> 2, x4 = id % ns, y8 = id / ns;
     if (y8 >= (h >> 3)) return;
     const int y4 = y8 * 2;
+    if (y8 == 0) return;                                       /* picture border: never filtered (:383-390) */
+    /* the samples are requested before the CU data is known, so that both round trips overlap */
+    uint8_t *p = Y + (size_t)(y4 * 4 - 4) * w + x4 * 4;
+    uint32_t ra[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ra[k] = *(const uint32_t *)(p + (size_t)k * w);
     const DbkPart q = dbk_part<1>(out, w_ctu, x4, y4);
     if (!q.flag) return;
     const int qp = (dbk_qp_of(out, w_ctu, x4, y4 - 1) + q.qp + 1) >> 1;
     int m[4][8];
-    uint8_t *p = Y + (size_t)(y4 * 4 - 4) * w + x4 * 4;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const uint32_t a = *(const uint32_t *)(p + (size_t)k * w);
 #pragma unroll
-      for (int i = 0; i < 4; i++) m[i][k] = (a >> (8 * i)) & 255;
+      for (int i = 0; i < 4; i++) m[i][k] = (ra[k] >> (8 * i)) & 255;
     }
     if (dbk_segment_luma(m, qp, betaOff, tcOff)) {
 #pragma unroll
