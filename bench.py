@@ -98,9 +98,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # FCU_BENCH_REHEARSAL=1 (never set by the driver): rehearse the N>1 code path on a one-GPU box -- all ranks share
+    # cuda:0 and rendezvous over gloo, since RCCL refuses two ranks on one device.  The reported number is then not a
+    # scaling measurement and says so in `config`.
+    rehearsal = os.environ.get("FCU_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -154,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = pkg.sharding.reduce_step_time(dist, time.perf_counter() - t0, dev)
+    dt = pkg.sharding.reduce_step_time(dist, time.perf_counter() - t0, None if rehearsal else dev)
     kernel_ms, launches = eng.kernel_ms()
 
     ctus_per_step_gpu = n_chains * args.ctus_per_step
@@ -171,6 +180,7 @@ def main():
                                    f"(BASELINE configs[2]); {args.frames} frames x {len(qps)} QPs = {n_chains} chains/GPU, "
                                    f"{args.ctus_per_step} CTU/chain/step",
                        "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world,
+                       **({"rehearsal": "all ranks on one GPU over gloo: not a scaling measurement"} if rehearsal else {}),
                        "state": args.state if switches is None else
                        f"testing (Naive switches skip2Nx2N={switches[0].tolist()} terminate={switches[1].tolist()} from a Verifying step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
