@@ -4,8 +4,10 @@
 Workload (BASELINE.json configs[2]): 3840x2160 all-intra, QP {22,27,32,37}, full depth-0..3
 quadtree + chroma RDO, synthetic "textured" YUV, resident in HBM before the
 timed region.  A chain = (frame, QP) = one I slice, the unit HM decides strictly serially;
-`--frames` frames x 4 QPs chains run side by side, one wavefront each.  A *step* advances every
-chain by `--ctus-per-step` CTUs (compressCtu + encodeCtu replay per CTU) in one launch.
+`--frames` frames x 4 QPs chains are in flight per GPU, one wavefront each; by default that is twice the number of
+wave slots of the device, ordered longest (lowest QP) first, so that the slots the short high-QP chains free early are
+refilled by the hardware dispatcher.  A *step* advances every chain by `--ctus-per-step` CTUs (compressCtu + encodeCtu
+replay per CTU) in one launch.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; every rank
@@ -80,10 +82,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU (x4 QPs = chains per GPU)")
+    ap.add_argument("--frames", type=int, default=2048, help="frames per GPU (x4 QPs = chains per GPU)")
     ap.add_argument("--ctus-per-step", type=int, default=1)
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", choices=["frame", "qp"], default="qp",
+                    help="chain order inside a launch: frame-major or (default) QP-major, lowest QP = longest chains first; "
+                         "with more chains than wave slots the hardware dispatcher then backfills the slots freed by the "
+                         "short high-QP chains")
     ap.add_argument("--state", choices=["training", "testing"], default="training",
                     help="fork state of the timed steps.  training (default, the headline metric): exhaustive RDO.  "
                          "testing: the fork's Naive pruning; the OBF maps come from the device pre-pass, the first warm-up "
@@ -123,9 +129,14 @@ def main():
     # the 4 QP chains of a frame share its source planes
     out_bytes = pkg.engine.CTU_OUT_BYTES * total_ctus_chain
     frames, cache = [], {}
-    for ci, (seed, qp) in enumerate(pkg.sharding.chains_for_rank(args.frames, qps, rank)):
+    chain_list = pkg.sharding.chains_for_rank(args.frames, qps, rank)
+    if args.order == "qp":
+        chain_list = sorted(chain_list, key=lambda c: (c[1], c[0]))
+    seed_index = {}
+    for ci, (seed, qp) in enumerate(chain_list):
         if seed not in cache:
             cache[seed] = gen_textured_gpu(torch, dev, W, H, seed=seed)
+            seed_index[seed] = len(frames)
             frames.append(cache[seed])
         fr = cache[seed]
         rec = [torch.zeros_like(p) for p in fr]
@@ -141,7 +152,7 @@ def main():
         # untimed: OBF pre-pass of every frame, one Verifying step, switches from its counters, then Testing
         assert args.warmup >= 1, "--state testing uses the first warm-up step as the Verifying step"
         obf = [eng.obf_prepass(fr[0])[0][0].contiguous() for fr in frames]
-        chain_obf = [obf[ci // len(qps)] for ci in range(n_chains)]     # chains_for_rank: frame-major, QP-minor
+        chain_obf = [obf[seed_index[seed]] for seed, _ in chain_list]
         for ci in range(n_chains):
             eng.set_decision(ci, pkg.engine.VERIFYING, chain_obf[ci])
         step()
@@ -178,7 +189,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO "
                                    f"(BASELINE configs[2]); {args.frames} frames x {len(qps)} QPs = {n_chains} chains/GPU, "
-                                   f"{args.ctus_per_step} CTU/chain/step",
+                                   f"{args.ctus_per_step} CTU/chain/step, {args.order}-major order",
                        "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world,
                        **({"rehearsal": "all ranks on one GPU over gloo: not a scaling measurement"} if rehearsal else {}),
                        "state": args.state if switches is None else
