@@ -59,9 +59,12 @@ def gen_textured_gpu(torch, dev, w, h, seed):
     return f(Y), f(U), f(V)
 
 
-def cpu_baseline(frame_np, qp, budget_s=15.0):
+def cpu_baseline(frame_np, qp, budget_s=15.0, gpu_ctus=()):
     """The oracle (plain-C restatement of the reference loop) on this box's host cores, 1 thread,
-    on the first CTUs of the same workload.  A reported baseline, not the target."""
+    on the first CTUs of the same workload.  A reported baseline, not the target.  As the checker it also compares the
+    CU split decisions (depth per 4x4 partition, and the NxN flag of 8x8 CUs) the GPU published for the first CTUs of
+    the same chain -- the second half of BASELINE's metric."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hmo_py
     enc = hmo_py.Encoder(*frame_np, qp)
@@ -71,8 +74,19 @@ def cpu_baseline(frame_np, qp, budget_s=15.0):
         enc.compress_ctu(n)
         n += 1
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "CTUs/sec", "cores": 1, "kind": "port",
-            "sample": f"first {n} CTUs of frame 0 (3840x2160, QP{qp}), oracle/libhmo.so single thread, {dt:.1f}s"}
+    same = total = 0
+    for a, got in enumerate(gpu_ctus):
+        if a >= n:
+            break
+        want = enc.ctu_arrays(a)
+        same += int(((want["depth"] == got["depth"]) & (want["part_size"] == got["part_size"])).sum())
+        total += want["depth"].size
+    res = {"value": n / dt, "unit": "CTUs/sec", "cores": 1, "kind": "port",
+           "sample": f"first {n} CTUs of frame 0 (3840x2160, QP{qp}), oracle/libhmo.so single thread, {dt:.1f}s"}
+    match = {"ctus": min(n, len(gpu_ctus)), "partitions_equal": same, "partitions": total,
+             "frac": (same / total) if total else None,
+             "what": f"depth + part_size per 4x4 partition, GPU chain (frame 0, QP{qp}) vs the oracle on the same CTUs"}
+    return res, match
 
 
 def main():
@@ -201,7 +215,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             fr0 = [p.cpu().numpy() for p in frames[0]]
-            res["cpu_baseline"] = cpu_baseline(fr0, 32)
+            gpu_ctus = []
+            seed0 = chain_list[0][0]                      # frames[0]: the lowest seed in either chain order
+            if args.state == "training" and (seed0, 32) in chain_list:
+                c32 = chain_list.index((seed0, 32))
+                gpu_ctus = [eng.ctu_out(c32, a) for a in range(total_ctus_chain)]
+            res["cpu_baseline"], res["split_flag_match"] = cpu_baseline(fr0, 32, gpu_ctus=gpu_ctus)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
