@@ -236,6 +236,7 @@ struct Shared {
   /* explicit stacks of the serial tree walkers (a private array indexed by the stack pointer would live in scratch memory) */
   TU wk_st[4]; int wk_ci[4]; int wk_part[4], wk_child[4];
   double cand_cost[12];                             /* RMD candidate costs (CandCostList, TEncSearch.cpp:2289) */
+  uint64_t q_frac[5], t_frac;                       /* exact (Q15) bit counts of the chosen RQT subtrees per recursion level / of the last walk */
   double dec_j0, dec_j1; int dec_cnt, dec_flip;     /* fork hooks: J0 / J1 / Num_OBF / bPartition_True of the CU being closed */
 };
 
@@ -1494,7 +1495,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
   if (checkFirst && checkFull) checkSplit = 0;
   int checkTS = P.transform_skip && log2 == 2;
   if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
-  double singleCost = FCU_MAX_DOUBLE; uint32_t singleDist = 0, singleCbf = 0; int bestModeId = 0;
+  double singleCost = FCU_MAX_DOUBLE; uint32_t singleDist = 0, singleCbf = 0; int bestModeId = 0; uint64_t singleFrac = 0;
 
   if (checkFull) {
     if (checkTS) {
@@ -1506,11 +1507,11 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
         double tmpCost;
         if (modeId == 1 && tmpCbf == 0) tmpCost = FCU_MAX_DOUBLE;
         else {
-          { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); } FCU_TOC(E, t12_, 12); }
+          { FCU_TIC(t12_); FCU_SERIAL { const uint64_t f0 = g_S.cab[CAB_GOON].frac & 32767; g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); g_S.t_frac = g_S.cab[CAB_GOON].frac - f0; } FCU_TOC(E, t12_, 12); }
           tmpCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], tmpDist));
         }
         if (tmpCost < singleCost) {
-          singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId;
+          singleCost = tmpCost; singleDist = tmpDist; singleCbf = tmpCbf; bestModeId = modeId; singleFrac = FCU_UNI(g_S.t_frac);
           if (bestModeId == 0) { store_intra_result_qt(tu_key(tu), 0); FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); }
         }
         if (modeId == 0) FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
@@ -1528,6 +1529,8 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
          * from the same snapshot: take its levels, reconstruction, distortion, bits and coder state instead of
          * recomputing them (the candidate pools still hold them) */
         const int bv = reuseVc, N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = FCU_UNI((int)(g_S.vc_abs[bv] > 0));
+        FCU_SERIAL { g_S.t_frac = g_S.cab[CAB_LANE0 + g_S.vc_slot[bv]].frac - (g_S.cab[CAB_GOON].frac & 32767); }   /* the lane coder started from this snapshot */
+        singleFrac = FCU_UNI(g_S.t_frac);
         FCU_FOR_LANES {
           for (int i = lane; i < n2; i += 64) {
             G->qt_coef[0][layer][tu.off_y + i] = (cbf && (i >> 4) <= (g_S.vc_last[bv] >> 4)) ? G->p_qscan[i * g_S.pu_nvc + bv] : (int16_t)0;
@@ -1541,7 +1544,8 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
         tu_trial(cu, tu_key(tu), 0, (CAB_GOON), 0);
         singleDist = FCU_UNI(g_S.t_dist);
         if (checkSplit) singleCbf = FCU_UNI((uint32_t)((cu->cbf[0][part] >> trDepth) & 1));
-        { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); } FCU_TOC(E, t12_, 12); }
+        { FCU_TIC(t12_); FCU_SERIAL { const uint64_t f0 = g_S.cab[CAB_GOON].frac & 32767; g_S.vc_bits[0] = leaf_luma_bits(CAB_GOON, cu, tu_key(tu)); g_S.t_frac = g_S.cab[CAB_GOON].frac - f0; } FCU_TOC(E, t12_, 12); }
+        singleFrac = FCU_UNI(g_S.t_frac);
         singleCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], singleDist));
       }
     }
@@ -1550,7 +1554,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
     if constexpr (LEVEL < 3) {
       if (checkFull) { FCU_FOR_LANES { cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), &g_S.cab[CAB_GOON], lane); } FCU_FOR_LANES { cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane); } }
       else FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
-      FCU_SERIAL { g_S.q_dist[LEVEL + 1] = 0; g_S.q_cost[LEVEL + 1] = 0; }
+      FCU_SERIAL { g_S.q_dist[LEVEL + 1] = 0; g_S.q_cost[LEVEL + 1] = 0; g_S.q_frac[LEVEL + 1] = 0; }
       uint32_t splitCbf = 0;
       for (int i = 0; i < 4; i++) {
         TU c; tu_child(c, tu, i, 0);
@@ -1558,13 +1562,33 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
         splitCbf |= FCU_UNI((uint32_t)((cu->cbf[0][c.part] >> c.tr_depth) & 1));
       }
       const uint32_t splitDist = FCU_UNI(g_S.q_dist[LEVEL + 1]);
+      /* uiSplitBits = xGetIntraBitsQT of the whole split subtree from QT_TRAFO_ROOT (TEncSearch.cpp:1600-1606).  Every bin
+       * of that walk has already been counted, from the same state of its context, by the walks of the children's chosen
+       * encodings (child 0 starts from this node's root state and, when this node begins the CU, also carries the
+       * part-size / luma-mode bins; the subdivision and cbf contexts are indexed by TU size / depth), so the exact Q15
+       * count is this node's own subdivision flag plus the children's counts, and the coder after the last child is
+       * the coder after the walk.  Not for the NxN root, whose walk leaves out the luma modes its children count. */
+      const int sumBits = !(partSize == SIZE_NxN && trDepth == 0);
       FCU_FOR_LANES {
         if (splitCbf) for (int o = lane; o < tu.nparts; o += 64) cu->cbf[0][part + o] |= (uint8_t)(1 << trDepth);
-        cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
+        if (!sumBits) cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), lane);
       }
-      { FCU_TIC(t12_); FCU_SERIAL { g_S.vc_bits[0] = intra_bits_qt((CAB_GOON), cu, tu_key(tu), 1, 0); } FCU_TOC(E, t12_, 12); }
+      {
+        FCU_TIC(t12_);
+        FCU_SERIAL {
+          const uint64_t f0 = slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT)->frac & 32767;
+          if (sumBits) {
+            g_S.cab[CAB_GOON].frac = f0; g_S.cab[CAB_GOON].bins = 0;
+            if (log2 <= LOG2_MAXTU) cab_bin((CAB_GOON), 1, CTX_SUBDIV + 5 - log2);
+            g_S.cab[CAB_GOON].frac += g_S.q_frac[LEVEL + 1];
+            g_S.vc_bits[0] = (uint32_t)(g_S.cab[CAB_GOON].frac >> 15);
+          } else g_S.vc_bits[0] = intra_bits_qt((CAB_GOON), cu, tu_key(tu), 1, 0);
+          g_S.t_frac = g_S.cab[CAB_GOON].frac - f0;
+        }
+        FCU_TOC(E, t12_, 12);
+      }
       const double splitCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], splitDist));
-      if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; } return; }
+      if (splitCost < singleCost) { FCU_SERIAL { g_S.q_dist[LEVEL] += splitDist; g_S.q_cost[LEVEL] += splitCost; g_S.q_frac[LEVEL] += g_S.t_frac; } return; }
       FCU_FOR_LANES {
         cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, fullDepth, CI_QT_TRAFO_TEST), lane);
         for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(singleCbf << trDepth); cu->tskip[0][part + i] = (uint8_t)bestModeId; }
@@ -1575,7 +1599,7 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
       }
     }
   }
-  FCU_SERIAL { g_S.q_dist[LEVEL] += singleDist; g_S.q_cost[LEVEL] += singleCost; }
+  FCU_SERIAL { g_S.q_dist[LEVEL] += singleDist; g_S.q_cost[LEVEL] += singleCost; g_S.q_frac[LEVEL] += singleFrac; }
 }
 
 /* xSetIntraResultLumaQT, TEncSearch.cpp:1717-1757 (iterative) */
