@@ -11,6 +11,8 @@ CASES = [
     ("smooth", 136, 72, 27, 0),       # partial CTUs on both edges
     ("textured", 64, 128, 22, 0),
     ("mixed", 192, 64, 37, 2),        # slices of 2 CTUs
+    ("textured", 128, 64, 5, 0),      # ends of the QP range: many large levels / almost everything quantised away
+    ("mixed", 128, 64, 51, 0),
     ("smooth", 416, 240, 32, 0),      # BASELINE configs[0]: the 416x240 plumbing frame, QP 32 (seed as the survey's)
 ]
 

@@ -28,6 +28,8 @@ CASES = [
     ("textured", 128, 128, 22, 0),
     ("mixed", 136, 72, 37, 0),      # partial CTUs right and bottom (forced splits)
     ("mixed", 256, 64, 32, 2),      # SliceMode 1: two CTUs per slice
+    ("textured", 128, 64, 5, 0),    # ends of the QP range
+    ("mixed", 128, 64, 51, 0),
 ]
 
 
