@@ -5,7 +5,8 @@ does not depend on the world size."""
 
 def chains_for_rank(frames_per_gpu, qps, rank):
     """[(frame_seed, qp)] of one rank; seeds are globally unique so ranks never duplicate content."""
-    return [(7 + f + 1000 * rank, qp) for f in range(frames_per_gpu) for qp in qps]
+    stride = max(1000, frames_per_gpu)                     # ranks own disjoint seed ranges whatever the frame count
+    return [(7 + f + stride * rank, qp) for f in range(frames_per_gpu) for qp in qps]
 
 
 def slices_for_rank(n_ctu, slice_ctus, world, rank):

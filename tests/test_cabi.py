@@ -63,3 +63,15 @@ def test_slices_partition_a_frame(pkg):
             assert first % sl == 0 and n > 0
             seen += list(range(first, first + n))
     assert seen == list(range(n_ctu))
+
+
+def test_ranks_never_share_a_frame(pkg):
+    """bench.py's weak-scaling shards: every (frame seed, QP) chain belongs to exactly one rank, also when a rank owns
+    more frames than the default seed stride."""
+    for frames in (2, 1024, 2048, 5000):
+        seen = set()
+        for rank in range(8):
+            mine = pkg.sharding.chains_for_rank(frames, [22, 27, 32, 37], rank)
+            assert len(mine) == frames * 4 and len(set(mine)) == len(mine)
+            assert not (seen & set(mine))
+            seen |= set(mine)
