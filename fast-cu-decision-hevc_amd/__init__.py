@@ -5,6 +5,7 @@ Layout:
   csrc/fcu_kernels.hip   gfx950 kernel entry + C ABI (include/fcu.h) -> libfcu.so
   engine.py              ctypes binding + `TEncCu`-shaped host class
   synth.py               synthetic YUV generators
+  sequence.py            picture-level driver: fast-decision schedule, slices as chains, deblocking, .yuv I/O
 """
-from . import sharding, synth  # noqa: F401
+from . import sequence, sharding, synth  # noqa: F401
 from .engine import CuEngine, FrameParams, FcuError, lib_path, load_lib  # noqa: F401
