@@ -203,6 +203,26 @@ void ref_deblock(int betaOffsetDiv2, int tcOffsetDiv2)
   lf.destroy();
 }
 
+void ref_set_ctu_coeff(int ctu, int comp, const int *coef, int n)
+{ TCoeff *d = g_pic->getCtu(ctu)->getCoeff(ComponentID(comp)); for (int i = 0; i < n; i++) d[i] = coef[i]; }
+/* ---- CU syntax through the reference's own entropy coder (TEncEntropy / TEncSbac on the bit counter).  Each wrapper is
+ * the call TEncCu::xEncodeCU makes at that point (TEncCu.cpp:1679-1778); which CUs exist is decided by the caller from the
+ * depth array. */
+void ref_enc_split(int ctu, int part, int depth) { g_ent->encodeSplitFlag(g_pic->getCtu(ctu), part, depth); }      /* :1695 */
+void ref_enc_cu(int ctu, int part, int depth)
+{
+  TComDataCU *cu = g_pic->getCtu(ctu);
+  g_ent->encodePredMode(cu, part);                                                                                   /* :1752 */
+  g_ent->encodePartSize(cu, part, depth);                                                                            /* :1753 */
+  if (cu->isIntra(part) && cu->getPartitionSize(part) == SIZE_2Nx2N) g_ent->encodeIPCMInfo(cu, part);                /* :1755-1765 */
+  g_ent->encodePredInfo(cu, part);                                                                                   /* :1768 */
+  Bool dqp = false, cqa = false;
+  g_ent->encodeCoeff(cu, part, depth, dqp, cqa);                                                                     /* :1773 */
+}
+/* finishCU, TEncCu.cpp:1618-1640: the 0 terminating bit after the last CU of a CTU that does not end the slice */
+void ref_enc_finish(int ctu, int part, int lastCtuOfSlice)
+{ if (g_pic->getCtu(ctu)->isLastSubCUOfCtu(part) && !lastCtuOfSlice) g_ent->encodeTerminatingBit(0); }
+
 /* descend a TU tree: root = the CU at (zidx, depth) of CTU `ctu`; path[k] = child index at level k */
 struct TuChain { TComTURecurse *lv[5]; int n; };
 static TComTU *make_tu(TuChain &t, TComDataCU *cu, int zidx, int depth, int nsplit, const int *path, bool processLast)
