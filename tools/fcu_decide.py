@@ -58,10 +58,17 @@ def main():
         t0 = time.perf_counter()
         res = dec.decide_group(group)
         dt = time.perf_counter() - t0
-        for r in res:
+        for r, yuv in zip(res, group):
+            # PSNR of the (deblocked) reconstruction as TEncGOP::xCalculateAddPSNR reports it (TEncGOP.cpp): 10 log10(255^2 N / SSD)
+            psnr = []
+            for p, o in zip(r["rec"], yuv):
+                d = p.cpu().numpy().astype(np.int64) - o.astype(np.int64)
+                ssd = float((d * d).sum())
+                psnr.append(999.99 if ssd == 0 else 10.0 * np.log10(255.0 * 255.0 * d.size / ssd))
             hist = np.bincount(r["depth"].ravel(), minlength=4)
             print(f"POC {r['poc']:4d} {names[r['state']]:9s} skip2Nx2N={r['sw_skip'].tolist()} terminate={r['sw_term'].tolist()} "
-                  f"partitions at depth 0..3 = {hist.tolist()}  TU trials {r['tu_trials']}", flush=True)
+                  f"partitions at depth 0..3 = {hist.tolist()}  TU trials {r['tu_trials']}  "
+                  f"PSNR Y {psnr[0]:.4f} U {psnr[1]:.4f} V {psnr[2]:.4f} dB", flush=True)
             if rec_f:
                 seq.write_yuv420(rec_f, [p.cpu().numpy() for p in r["rec"]])
             if args.depth:
