@@ -331,6 +331,7 @@ int fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint
   const int w = c->sp.width, h = c->sp.height, w_ctu = (w + 63) / 64;
   const unsigned n0 = (unsigned)((w >> 3) * (h >> 2)), n1 = (unsigned)((w >> 2) * (h >> 3));
   hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+  struct EventGuard { hipEvent_t *e; ~EventGuard() { for (int i = 0; i < 3; i++) if (e[i]) hipEventDestroy(e[i]); } } guard{ e };
   if (kernel_ms2) { for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&e[i])); HIPCHK(hipEventRecord(e[0], st)); }
   /* all vertical edges of the picture before the first horizontal one (TComLoopFilter.cpp:133-154): stream order */
   hipLaunchKernelGGL(dbk_pass<0>, dim3((n0 + DBK_THREADS - 1) / DBK_THREADS), dim3(DBK_THREADS), 0, st, dev_out, dev_rec_y, dev_rec_u, dev_rec_v, w, h, w_ctu, beta_offset_div2, tc_offset_div2);
@@ -342,7 +343,6 @@ int fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint
     HIPCHK(hipEventRecord(e[2], st));
     HIPCHK(hipStreamSynchronize(st));
     hipEventElapsedTime(&kernel_ms2[0], e[0], e[1]); hipEventElapsedTime(&kernel_ms2[1], e[1], e[2]);
-    for (int i = 0; i < 3; i++) hipEventDestroy(e[i]);
   }
   return FCU_OK;
 }

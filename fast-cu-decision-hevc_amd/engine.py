@@ -157,6 +157,7 @@ class CuEngine:
         self.width, self.height, self.max_chains, self.device = width, height, max_chains, device
         self.h = C.c_void_p()
         self._keep = {}
+        self._keep_obf = {}
         self.create()
 
     # -- TEncCu::create
@@ -277,7 +278,6 @@ class CuEngine:
         if obf is not None:
             assert obf.is_contiguous() and obf.dtype == self.torch.int16 and tuple(obf.shape) == (self.height // 4, self.width // 4)
             dp.dev_obf = obf.data_ptr()
-            self._keep_obf = getattr(self, "_keep_obf", {})
             self._keep_obf[chain] = obf
         self._chk(self.lib.fcu_chain_set_decision(self.h, chain, C.byref(dp)), "fcu_chain_set_decision")
 
@@ -306,6 +306,7 @@ class CuEngine:
             self.lib.fcu_destroy(self.h)
             self.h = C.c_void_p()
         self._keep = {}
+        self._keep_obf = {}
 
     def __del__(self):
         try:

@@ -152,6 +152,7 @@ int  fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uin
                  int beta_offset_div2, int tc_offset_div2, float *kernel_ms2, void *hip_stream);
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);
+/* text of the last failure (one process-wide buffer: calls on one context are not re-entrant; use one context per host thread) */
 const char *fcu_last_error(void);
 
 #ifdef __cplusplus
