@@ -213,7 +213,7 @@ def main():
                          "traffic": measured_traffic(n_chains, args.ctus_per_step) if switches is None else None,
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N=1 only
             fr0 = [p.cpu().numpy() for p in frames[0]]
             gpu_ctus = []
             seed0 = chain_list[0][0]                      # frames[0]: the lowest seed in either chain order
