@@ -189,6 +189,8 @@ struct alignas(16) Scratch {
   int32_t p_lscan[POOL]; int16_t p_qscan[POOL];
   /* RDOQ locals (TComTrQuant.cpp:2082-2095), same interleaving */
   RdoqRec r_rec[POOL]; double r_cg[MAXVC * 64];
+  /* 64x64 first pass: per-candidate reconstruction and levels of the whole PU (candidates advance side by side) */
+  uint8_t c64_rec[5][CTU * CTU]; alignas(16) int16_t c64_coef[5][CTU * CTU];
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
@@ -236,6 +238,7 @@ struct Shared {
   /* explicit stacks of the serial tree walkers (a private array indexed by the stack pointer would live in scratch memory) */
   TU wk_st[4]; int wk_ci[4]; int wk_part[4], wk_child[4];
   double cand_cost[12];                             /* RMD candidate costs (CandCostList, TEncSearch.cpp:2289) */
+  uint32_t c64_dist[5]; uint8_t c64_cbf[5][4];      /* 64x64 first pass: per-candidate distortion / cbf of its four TUs */
   uint64_t q_frac[5], t_frac;                       /* exact (Q15) bit counts of the chosen RQT subtrees per recursion level / of the last walk */
   double dec_j0, dec_j1; int dec_cnt, dec_flip;     /* fork hooks: J0 / J1 / Num_OBF / bPartition_True of the CU being closed */
 };
@@ -1864,6 +1867,124 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
   }
 }
 
+/* First pass of a 64x64 PU (TEncSearch.cpp:2440-2516, where xRecurIntraCodingLumaQT can only code it as four 32x32 TUs).
+ * The candidates share the snapshot they start from and nothing else, so they advance side by side: for each of the four
+ * TUs in turn, the prediction of every candidate from that candidate's own reconstruction of the earlier TUs (swapped
+ * into the picture plane for build_ref), then one batched transform, RDOQ with one candidate per lane on its own running
+ * coder, reconstruction and bit count.  A candidate's bits are the Q15 sum of its four TU walks (see recur_luma_qt). */
+FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU root = tu_of_key(FCU_UNI(root_k));
+  Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, nc = g_S.n_rd, log2 = 5, N = 32, n2 = N * N, partSize = cu->part_size[root.part];
+  FCU_CHECK(nc <= 5 && nc * n2 <= POOL && root.log2 == 6);
+  const int qbits = rdoq_qbits(log2, P.qp), qscale = k_quant_scales[P.qp % 6];
+  uint8_t *recpic = E.C->rec[0] + cu->y * E.C->stride[0] + cu->x; const int rs = E.C->stride[0];
+  FCU_FOR_LANES {
+    if (lane < nc) { const int c = CAB_LANE0 + lane; cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST)); cab_reset_bits(c); g_S.c64_dist[lane] = 0; }
+  }
+  for (int k = 0; k < 4; k++) {
+    TU tu; tu_child(tu, root, k, 0);
+    const uint8_t *org = G->org[d].y + tu.y * 64 + tu.x;
+    for (int cand = 0; cand < nc; cand++) {
+      const int mode = g_S.rd_mode[cand], filt = use_filtered_ref(mode, log2, 1);
+      if (k) {
+        FCU_FOR_LANES {                                      /* this candidate's earlier TUs become the neighbourhood */
+          for (int i = lane; i < k * n2; i += 64) {
+            const int j = i >> 10, q = i & (n2 - 1), yy = (j >> 1) * N + (q >> log2), xx = (j & 1) * N + (q & (N - 1));
+            recpic[yy * rs + xx] = G->c64_rec[cand][yy * 64 + xx];
+          }
+        }
+      }
+      build_ref(0, cu->x + tu.x, cu->y + tu.y, log2, filt);
+      FCU_FOR_LANES {
+        const uint8_t *r = filt ? g_S.reff : g_S.ref; const int dc = g_S.dc;
+        for (int i = lane; i < n2; i += 64) {
+          const int y = i >> log2, x = i & (N - 1);
+          const int v = pred_pixel(r, log2, mode, 1, dc, x, y);
+          G->p_pred[cand * n2 + i] = (uint8_t)v; G->p_resi[cand * n2 + i] = (int16_t)(org[y * 64 + x] - v);
+        }
+      }
+    }
+    FCU_FOR_LANES { if (lane < nc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + cnd * n2, 0, i - cnd * n2); } }); }
+    FCU_FOR_LANES {
+      by_log2(log2, [&](auto L) {
+        for (int i = lane; i < nc * n2; i += 64) {
+          const int v = i / n2, p = i - v * n2;
+          const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v], log2, 0) * 4 + log2 - 2];
+          const int32_t t = fwd2<decltype(L)::value>(G->p_tmp + v * n2, 0, p);
+          const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
+          G->p_lscan[sp * nc + v] = ld;
+          if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
+        }
+      });
+    }
+    FCU_FOR_LANES {                                          /* RDOQ: one candidate per lane, priced against its own coder */
+      if (lane < nc) {
+        RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
+        const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + lane, G->p_lscan + lane, G->p_qscan + lane, nc, g_S.vc_last[lane], log2, 0,
+                                     coef_scan_idx(g_S.rd_mode[lane], log2, 0), CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0), P, rrec, rcg);
+        g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last; g_S.vc_dist[lane] = 0;
+      }
+      if (lane == 0) E.C->n_tu_trials += (unsigned long long)nc;
+    }
+    FCU_FOR_LANES {                                          /* levels kept per candidate (scan order) + dequantisation */
+      const DeqParams dq = deq_params(log2, P.qp);
+      for (int i = lane; i < nc * n2; i += 64) {
+        const int v = i / n2, p = i - v * n2;
+        const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v], log2, 0) * 4 + log2 - 2];
+        const int sp = iscan[p];
+        const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nc + v] : 0;
+        G->c64_coef[v][tu.off_y + sp] = (int16_t)q;
+        G->p_tmp[v * n2 + tr_index(p, log2)] = dequant1(q, dq);
+      }
+    }
+    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int v = i / n2; G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, 0, i - v * n2); } }); }
+    FCU_FOR_LANES {
+      by_log2(log2, [&](auto L) {
+        for (int i = lane; i < nc * n2; i += 64) {
+          const int v = i / n2, p = i - v * n2, y = p >> log2, x = p & (N - 1);
+          const int res = g_S.vc_abs[v] > 0 ? inv2<decltype(L)::value>(G->p_tcoef + v * n2, 0, p) : 0;
+          const int r = clip8(G->p_pred[i] + res);
+          G->c64_rec[v][(tu.y + y) * 64 + tu.x + x] = (uint8_t)r;
+          const int e = org[y * 64 + x] - r;
+          FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+        }
+      });
+    }
+    FCU_FOR_LANES {                                          /* the TU's walk (leaf_luma_bits) on the candidate's running coder */
+      if (lane < nc) {
+        const int c = CAB_LANE0 + lane, mode = g_S.rd_mode[lane], cbf = g_S.vc_abs[lane] > 0;
+        if (tu.part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
+        if (tu.part == 0) code_luma_dir_bits(c, mode, g_S.preds);
+        if (log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize)) cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
+        cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+        if (cbf) code_coeff_nxn<0>(c, G->p_qscan + lane, nc, g_S.vc_lsp[lane], log2, 0, coef_scan_idx(mode, log2, 0), 0, P, g_S.lane_abs[lane]);
+        g_S.c64_dist[lane] += g_S.vc_dist[lane]; g_S.c64_cbf[lane][k] = (uint8_t)cbf;
+      }
+    }
+  }
+  FCU_SERIAL {                                               /* strict '<' in candidate order (TEncSearch.cpp:2488-2510) */
+    double best = FCU_MAX_DOUBLE; int bv = 0;
+    for (int cand = 0; cand < nc; cand++) {
+      const double c = rd_cost(P, (uint32_t)(g_S.cab[CAB_LANE0 + cand].frac >> 15), g_S.c64_dist[cand]);
+      if (c < best) { best = c; bv = cand; }
+    }
+    g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.c64_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv];
+  }
+  {                                                          /* xSetIntraResultLumaQT + decision snapshot of the winner */
+    const int bv = g_S.pu_best_vc;
+    Yuv *reco = &G->reco[d][1 - g_S.reco_best_idx[d]];
+    const int any = g_S.c64_cbf[bv][0] | g_S.c64_cbf[bv][1] | g_S.c64_cbf[bv][2] | g_S.c64_cbf[bv][3];
+    FCU_FOR_LANES {
+      for (int i = lane; i < CTU * CTU; i += 64) { cu->coef[0][i] = G->c64_coef[bv][i]; reco->y[i] = G->c64_rec[bv][i]; }
+      for (int i = lane; i < root.nparts; i += 64) {
+        G->tmp_tr_idx[i] = 1; G->tmp_cbf[i] = (uint8_t)((g_S.c64_cbf[bv][i / (root.nparts >> 2)] << 1) | any); G->tmp_tskip[i] = 0;
+      }
+    }
+  }
+}
+
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
@@ -1882,7 +2003,8 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
     { FCU_TIC(t_); rmd(cu, tu_key(tu)); FCU_TOC(E, t_, 0); }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
     if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }
-    else {                                                   /* 64x64: four 32x32 TUs per candidate, sequential */
+    else if (g_S.n_rd <= 5) { FCU_TIC(t_); pu_first_pass_64(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }   /* 64x64: four 32x32 TUs, candidates side by side */
+    else {                                                   /* more candidates than the pools hold: one after the other */
       FCU_SERIAL { g_S.pu_best_cost = FCU_MAX_DOUBLE; g_S.pu_best_mode = 0; g_S.pu_best_dist = 0; }
       const int nc = g_S.n_rd;
       for (int m = 0; m < nc; m++) {
