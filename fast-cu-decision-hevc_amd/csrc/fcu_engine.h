@@ -191,6 +191,7 @@ struct alignas(16) Scratch {
   RdoqRec r_rec[POOL]; double r_cg[MAXVC * 64];
   /* 64x64 first pass: per-candidate reconstruction and levels of the whole PU (candidates advance side by side) */
   uint8_t c64_rec[5][CTU * CTU]; alignas(16) int16_t c64_coef[5][CTU * CTU];
+  Cabac c64_state[5][4]; uint32_t c64_distk[5][4];   /* ... and its coder / distortion after each of the four TUs */
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
@@ -238,7 +239,7 @@ struct Shared {
   /* explicit stacks of the serial tree walkers (a private array indexed by the stack pointer would live in scratch memory) */
   TU wk_st[4]; int wk_ci[4]; int wk_part[4], wk_child[4];
   double cand_cost[12];                             /* RMD candidate costs (CandCostList, TEncSearch.cpp:2289) */
-  uint32_t c64_dist[5]; uint8_t c64_cbf[5][4];      /* 64x64 first pass: per-candidate distortion / cbf of its four TUs */
+  uint32_t c64_dist[5]; uint8_t c64_cbf[5][4]; int c64_valid;      /* 64x64 first pass: per-candidate distortion / cbf of its four TUs */
   uint64_t q_frac[5], t_frac;                       /* exact (Q15) bit counts of the chosen RQT subtrees per recursion level / of the last walk */
   double dec_j0, dec_j1; int dec_cnt, dec_flip;     /* fork hooks: J0 / J1 / Num_OBF / bPartition_True of the CU being closed */
 };
@@ -1543,6 +1544,30 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
           cab_copy(&g_S.cab[CAB_GOON], &g_S.cab[CAB_LANE0 + g_S.vc_slot[bv]], lane);
         }
         singleDist = FCU_UNI(g_S.vc_dist[bv]); singleCbf = (uint32_t)cbf; singleCost = FCU_UNI(g_S.vc_cost[bv]);
+      } else if (reuseVc <= -2) {
+        /* 32x32 TU k of a 64x64 PU whose earlier TUs all kept the first pass's un-split result: coder and neighbourhood
+         * are what they were in the first pass (pu_first_pass_64), so this trial would reproduce that pass's TU k of the
+         * winning candidate -- levels, reconstruction, distortion, bits and coder state are taken from there */
+        const int k = -2 - reuseVc, bv = FCU_UNI(g_S.pu_best_vc), N = 1 << log2, n2 = N * N, layer = LOG2_MAXTU - log2, cbf = FCU_UNI((int)g_S.c64_cbf[bv][k]);
+        FCU_SERIAL {
+          const uint64_t fprev = k ? G->c64_state[bv][k - 1].frac : (slot_ptr(E, d, CI_CURR_BEST)->frac & 32767);
+          g_S.t_frac = G->c64_state[bv][k].frac - fprev;
+          g_S.vc_bits[0] = (uint32_t)(((fprev & 32767) + g_S.t_frac) >> 15);
+          g_S.t_dist = G->c64_distk[bv][k];
+        }
+        singleFrac = FCU_UNI(g_S.t_frac);
+        FCU_FOR_LANES {
+          for (int i = lane; i < n2; i += 64) {
+            G->qt_coef[0][layer][tu.off_y + i] = G->c64_coef[bv][tu.off_y + i];
+            const int o = (tu.y + (i >> log2)) * 64 + tu.x + (i & (N - 1));
+            G->qt_rec[layer].y[o] = G->c64_rec[bv][o];
+          }
+          for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trDepth; cu->cbf[0][part + i] = (uint8_t)(cbf << trDepth); }
+          cab_copy(&g_S.cab[CAB_GOON], &G->c64_state[bv][k], lane);
+        }
+        FCU_SERIAL { g_S.cab[CAB_GOON].frac = (g_S.cab[CAB_GOON].frac & 32767) + ((uint64_t)g_S.vc_bits[0] << 15); }
+        singleDist = FCU_UNI(g_S.t_dist); singleCbf = (uint32_t)cbf;
+        singleCost = FCU_UNI(rd_cost(P, g_S.vc_bits[0], singleDist));
       } else {
         tu_trial(cu, tu_key(tu), 0, (CAB_GOON), 0);
         singleDist = FCU_UNI(g_S.t_dist);
@@ -1559,10 +1584,12 @@ FCU_DEV FCU_NOINLINE void recur_luma_qt(CuObj *cu, uint32_t tu_k, int checkFirst
       else FCU_FOR_LANES cab_copy(slot_ptr(E, fullDepth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
       FCU_SERIAL { g_S.q_dist[LEVEL + 1] = 0; g_S.q_cost[LEVEL + 1] = 0; g_S.q_frac[LEVEL + 1] = 0; }
       uint32_t splitCbf = 0;
+      int chainOk = LEVEL == 0 && log2 == 6 && !checkFirst && FCU_UNI(g_S.c64_valid);   /* see the reuse branch above */
       for (int i = 0; i < 4; i++) {
         TU c; tu_child(c, tu, i, 0);
-        recur_luma_qt<LEVEL + 1>(cu, tu_key(c), checkFirst);
+        recur_luma_qt<LEVEL + 1>(cu, tu_key(c), checkFirst, chainOk ? -2 - i : -1);
         splitCbf |= FCU_UNI((uint32_t)((cu->cbf[0][c.part] >> c.tr_depth) & 1));
+        chainOk = chainOk && FCU_UNI((int)cu->tr_idx[c.part]) == c.tr_depth;
       }
       const uint32_t splitDist = FCU_UNI(g_S.q_dist[LEVEL + 1]);
       /* uiSplitBits = xGetIntraBitsQT of the whole split subtree from QT_TRAFO_ROOT (TEncSearch.cpp:1600-1606).  Every bin
@@ -1961,6 +1988,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
         cab_bin(c, cbf, CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
         if (cbf) code_coeff_nxn<0>(c, G->p_qscan + lane, nc, g_S.vc_lsp[lane], log2, 0, coef_scan_idx(mode, log2, 0), 0, P, g_S.lane_abs[lane]);
         g_S.c64_dist[lane] += g_S.vc_dist[lane]; g_S.c64_cbf[lane][k] = (uint8_t)cbf;
+        G->c64_distk[lane][k] = g_S.vc_dist[lane]; cab_copy1(&G->c64_state[lane][k], &g_S.cab[c]);
       }
     }
   }
@@ -1971,6 +1999,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
       if (c < best) { best = c; bv = cand; }
     }
     g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.c64_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv];
+    g_S.c64_valid = 1;
   }
   {                                                          /* xSetIntraResultLumaQT + decision snapshot of the winner */
     const int bv = g_S.pu_best_vc;
@@ -2000,6 +2029,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
   for (int pu = 0; pu < numPU; pu++) {
     TU tu; if (initTrDepth == 0) tu = root; else tu_child(tu, root, pu, 0);
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
+    FCU_SERIAL g_S.c64_valid = 0;
     { FCU_TIC(t_); rmd(cu, tu_key(tu)); FCU_TOC(E, t_, 0); }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
     if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }
