@@ -2183,29 +2183,39 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     checkTS = checkTS && (tu.log2 == 2);
     if (checkTS) { int nb = 0; const int maxp = tu.part + (tu.c_code_all ? 1 : 4); for (int p = tu.part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
   }
-  const int tsv = checkTS ? 2 : 1, nvc = 5 * tsv;
+  const int tsv = checkTS ? 2 : 1;
+  /* Without a transform-skip trial nothing is coded between the two components (the bits are counted on the whole tree
+   * afterwards), so Cb and Cr of a mode are priced against the same coder state and are independent of each other: both
+   * go through one round, ten variants side by side.  With the trial the coder moves on after Cb's winner
+   * (TEncSearch.cpp:1985-2058) and the components stay in sequence; so do 32x32 blocks, which would not fit the pools. */
+  const int perRound = (tsv == 1 && 10 * n2 <= POOL) ? 2 : 1;
+  const int nm = 5 * perRound, nvc = nm * tsv;                  /* prediction blocks / variants of a round */
   const int qbits = rdoq_qbits(log2, P.qp_c), qscale = k_quant_scales[P.qp_c % 6];
   const int subPart = tu_part_c(tu), nPartsC = tu_nparts_c(tu);
-  for (int comp = 1; comp < 3; comp++) {
+  const int lumaDir = cu->intra_dir[0][tu.part & ~3];
+  for (int comp0 = 1; comp0 < 3; comp0 += perRound) {
     const int px = (cu->x >> 1) + tu.cx, py = (cu->y >> 1) + tu.cy;
-    const uint8_t *org = yuv_plane(&G->org[d], comp) + tu.cy * 32 + tu.cx;
-    chroma_leaf_refs5(E, cu, comp, px, py, log2);
-    FCU_FOR_LANES {
-      for (int i = lane; i < 5 * n2; i += 64) {
-        const int m = i / n2, p = i - m * n2, y = p >> log2, x = p & (N - 1);
-        const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
-        const int pr = pred_pixel(g_S.ref5[m], log2, mode, 0, g_S.dc5[m], x, y);
-        G->p_pred[i] = (uint8_t)pr; G->p_resi[i] = (int16_t)(org[y * 32 + x] - pr);
+    for (int cc = 0; cc < perRound; cc++) {
+      const int comp = comp0 + cc;
+      const uint8_t *org = yuv_plane(&G->org[d], comp) + tu.cy * 32 + tu.cx;
+      chroma_leaf_refs5(E, cu, comp, px, py, log2);
+      FCU_FOR_LANES {
+        for (int i = lane; i < 5 * n2; i += 64) {
+          const int m = i / n2, p = i - m * n2, y = p >> log2, x = p & (N - 1);
+          const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
+          const int pr = pred_pixel(g_S.ref5[m], log2, mode, 0, g_S.dc5[m], x, y);
+          G->p_pred[cc * 5 * n2 + i] = (uint8_t)pr; G->p_resi[cc * 5 * n2 + i] = (int16_t)(org[y * 32 + x] - pr);
+        }
       }
     }
-    FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < 5 * n2; i += 64) { const int m = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + m * n2, 0, i - m * n2); } }); }
+    FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nm * n2; i += 64) { const int b = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + b * n2, 0, i - b * n2); } }); }
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nvc * n2; i += 64) {
-          const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv;
-          const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
+          const int v = i / n2, p = i - v * n2, b = v / tsv, ts = v % tsv, m = b % 5, comp = comp0 + b / 5;
+          const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
           const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
-          const int32_t t = ts ? ((int32_t)G->p_resi[m * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + m * n2, 0, p);
+          const int32_t t = ts ? ((int32_t)G->p_resi[b * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + b * n2, 0, p);
           const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
           G->p_lscan[sp * nvc + v] = ld;
           if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
@@ -2215,8 +2225,8 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_TIC(t13_);
     FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
       if (lane < nvc) {
-        const int m = lane / tsv;
-        const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
+        const int b = lane / tsv, m = b % 5, comp = comp0 + b / 5;
+        const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
         const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
         g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
@@ -2228,8 +2238,8 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {                                      /* levels back to raster order + dequantisation */
       const DeqParams dq = deq_params(log2, P.qp_c);
       for (int i = lane; i < nvc * n2; i += 64) {
-        const int v = i / n2, p = i - v * n2, m = v / tsv;
-        const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
+        const int v = i / n2, p = i - v * n2, b = v / tsv, m = b % 5, comp = comp0 + b / 5;
+        const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
         const int sp = iscan[p];
         const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
@@ -2248,10 +2258,11 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nvc * n2; i += 64) {
-          const int v = i / n2, p = i - v * n2, m = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+          const int v = i / n2, p = i - v * n2, b = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+          const uint8_t *org = yuv_plane(&G->org[d], comp0 + b / 5) + tu.cy * 32 + tu.cx;
           int res = 0;
           if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2<decltype(L)::value>(G->p_tcoef + v * n2, 0, p);
-          const int r = clip8(G->p_pred[m * n2 + p] + res);
+          const int r = clip8(G->p_pred[b * n2 + p] + res);
           G->p_rec[i] = (uint8_t)r;
           const int e = org[y * 32 + x] - r;
           FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
@@ -2261,9 +2272,10 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {                                      /* per mode: transform-skip decision (TEncSearch.cpp:1985-2058) */
       if (lane < 5) {
         const int m = lane; int bestTs = 0;
-        const int mode = g_S.c_modes[m] == DM_CHROMA ? cu->intra_dir[0][tu.part & ~3] : g_S.c_modes[m];
-        uint32_t dsel = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * tsv]);
-        if (tsv == 2) {
+        const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
+        if (tsv == 2) {                                      /* one component per round: variants 2m (coded) and 2m+1 (skipped) */
+          const int comp = comp0;
+          uint32_t dsel = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2]);
           const uint32_t d0 = dsel, d1 = (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[m * 2 + 1]);
           const int c0 = CAB_LANE0 + 5 + m, c1 = CAB_LANE0 + 10 + m;
           cab_copy1(&g_S.cab[c0], &g_S.cab[CAB_LANE0 + m]); cab_reset_bits(c0);
@@ -2276,20 +2288,22 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
             cost1 = rd_cost(P, cab_bits(c1), d1);
           }
           if (cost1 < cost0) { bestTs = 1; dsel = d1; cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c1]); } else cab_copy1(&g_S.cab[CAB_LANE0 + m], &g_S.cab[c0]);
+          g_S.cm_dist[m] += dsel;
+        } else {
+          for (int cc = 0; cc < perRound; cc++) g_S.cm_dist[m] += (uint32_t)(P.chroma_weight * (double)g_S.vc_dist[cc * 5 + m]);
         }
         g_S.uni[m] = bestTs;
-        g_S.cm_dist[m] += dsel;
       }
     }
     FCU_FOR_LANES {                                      /* publish the chosen variant into the mode's buffers */
-      for (int i = lane; i < 5 * n2; i += 64) {
-        const int m = i / n2, p = i - m * n2, v = m * tsv + g_S.uni[m], cbf = g_S.vc_abs[v] > 0;
+      for (int i = lane; i < nm * n2; i += 64) {
+        const int b = i / n2, p = i - b * n2, m = b % 5, comp = comp0 + b / 5, v = b * tsv + g_S.uni[m], cbf = g_S.vc_abs[v] > 0;
         G->cm[m].coef[comp - 1][tu.off_c + p] = (cbf && (p >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[p * nvc + v] : (int16_t)0;
         uint8_t *ov = comp == 1 ? G->cm[m].u : G->cm[m].v;
         ov[(tu.cy + (p >> log2)) * 32 + tu.cx + (p & (N - 1))] = G->p_rec[v * n2 + p];
       }
-      for (int i = lane; i < 5 * nPartsC; i += 64) {
-        const int m = i / nPartsC, p = i - m * nPartsC, v = m * tsv + g_S.uni[m];
+      for (int i = lane; i < nm * nPartsC; i += 64) {
+        const int b = i / nPartsC, p = i - b * nPartsC, m = b % 5, comp = comp0 + b / 5, v = b * tsv + g_S.uni[m];
         G->cm[m].cbf[comp - 1][subPart + p] = (uint8_t)((g_S.vc_abs[v] > 0 ? 1 : 0) << trDepth);
         G->cm[m].tskip[comp - 1][subPart + p] = (uint8_t)g_S.uni[m];
       }
