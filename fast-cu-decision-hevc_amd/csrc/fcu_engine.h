@@ -1188,7 +1188,7 @@ FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, 
   if (bLuma) {
     if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, cu->part_size[0] == SIZE_2Nx2N, CTX_PARTSIZE);
     if (cu->part_size[0] == SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(c, cu, 0, 0); }
-    else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(c, cu, part, 0); }
+    else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part & (q - 1)) == 0) code_intra_dir_luma(c, cu, part, 0); }
   }
   if (bChroma && part == 0) code_intra_dir_chroma(c, cu->intra_dir[1][part]);
 }
@@ -1212,7 +1212,7 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, uint32_t tu
   const int part = tu.part, partSize = cu->part_size[0], log2 = tu.log2;
   cab_reset_bits(c);
   if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
-  if (partSize == SIZE_2Nx2N ? (part == 0) : (tu.tr_depth > 0 && (part % (cu->nparts >> 2)) == 0))
+  if (partSize == SIZE_2Nx2N ? (part == 0) : (tu.tr_depth > 0 && (part & ((cu->nparts >> 2) - 1)) == 0))
     code_luma_dir_bits(c, cu->intra_dir[0][part], g_S.preds);
   if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(cu->depth[part], cu->part_size[part]))
     cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
@@ -1761,7 +1761,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
   const int partSize = cu->part_size[part];
   int checkTS = P.transform_skip && log2 == 2;
   if (P.ts_fast) checkTS = checkTS && (partSize == SIZE_NxN);
-  const int nc = g_S.n_rd, tsv = checkTS ? 2 : 1, nvc = nc * tsv;
+  const int nc = g_S.n_rd, tsv = checkTS ? 2 : 1, tss = tsv - 1, nvc = nc * tsv;   /* v / tsv == v >> tss, v % tsv == v & tss */
   FCU_CHECK(nvc <= MAXVC && nvc * n2 <= POOL && (MAXLC % 2) == 0);
   const int qbits = rdoq_qbits(log2, P.qp), qscale = k_quant_scales[P.qp % 6];
   const int useDst = log2 == 2;
@@ -1782,7 +1782,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
     est_build(CAB_CUR0 + d, lane);
     by_log2(log2, [&](auto L) {
       for (int i = lane; i < nvc * n2; i += 64) {
-        const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv;
+        const int v = i / n2, p = i - v * n2, cnd = (v >> tss), ts = (v & tss);
         const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
         const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + cnd * n2, useDst, p);
         const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
@@ -1794,7 +1794,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
   FCU_TIC(t2_);
   FCU_FOR_LANES {                                            /* RDOQ: one virtual candidate per lane */
     if (lane < nvc) {
-      const int mode = g_S.rd_mode[lane / tsv];
+      const int mode = g_S.rd_mode[(lane >> tss)];
       RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
       const RdoqOut o = rdoq<0, 1>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
@@ -1808,16 +1808,16 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
     const DeqParams dq = deq_params(log2, P.qp);
     for (int i = lane; i < nvc * n2; i += 64) {
       const int v = i / n2, p = i - v * n2;
-      const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v / tsv], log2, 0) * 4 + log2 - 2];
+      const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[(v >> tss)], log2, 0) * 4 + log2 - 2];
       const int sp = iscan[p];
       const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-      G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
+      G->p_tmp[((v & tss)) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
     }
   }
   FCU_FOR_LANES {
     by_log2(log2, [&](auto L) {
       for (int i = lane; i < nvc * n2; i += 64) {
-        const int v = i / n2, p = i - v * n2, ts = v % tsv;
+        const int v = i / n2, p = i - v * n2, ts = (v & tss);
         if (ts) { const int s = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (s - 1))) >> s; }
         else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, useDst, p);
       }
@@ -1826,7 +1826,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
   FCU_FOR_LANES {
     by_log2(log2, [&](auto L) {
       for (int i = lane; i < nvc * n2; i += 64) {
-        const int v = i / n2, p = i - v * n2, cnd = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+        const int v = i / n2, p = i - v * n2, cnd = (v >> tss), ts = (v & tss), y = p >> log2, x = p & (N - 1);
         int res = 0;
         if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2<decltype(L)::value>(G->p_tcoef + v * n2, useDst, p);
         const int r = clip8(G->p_pred[cnd * n2 + p] + res);
@@ -1848,7 +1848,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {
       const int vc = vbase + lane;
       if (lane < MAXLC && vc < nvc) {
-        const int cnd = vc / tsv, ts = vc % tsv, mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[vc] > 0;
+        const int cnd = (vc >> tss), ts = (vc & tss), mode = g_S.rd_mode[cnd], cbf = g_S.vc_abs[vc] > 0;
         const int slot = (slotBase + lane) % MAXLC;
         double cost;
         g_S.vc_slot[vc] = (uint8_t)slot;
@@ -1877,12 +1877,12 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
         if (tsv == 2 && g_S.vc_cost[v + 1] < c) { v = v + 1; c = g_S.vc_cost[v]; }
         if (c < best) { best = c; bv = v; }
       }
-      g_S.pu_nvc = nvc; g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[bv / tsv];
+      g_S.pu_nvc = nvc; g_S.pu_best_vc = bv; g_S.pu_best_cost = best; g_S.pu_best_dist = g_S.vc_dist[bv]; g_S.pu_best_mode = g_S.rd_mode[(bv >> tss)];
     }
   }
   FCU_TOC(E, t3_, 3);
   {                                                          /* xSetIntraResultLumaQT + decision snapshot */
-    const int bv = g_S.pu_best_vc, ts = bv % tsv, cbf = g_S.vc_abs[bv] > 0;
+    const int bv = g_S.pu_best_vc, ts = (bv & tss), cbf = g_S.vc_abs[bv] > 0;
     Yuv *reco = &G->reco[d][1 - g_S.reco_best_idx[d]];
     FCU_FOR_LANES {
       for (int i = lane; i < n2; i += 64) {
@@ -2183,7 +2183,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     checkTS = checkTS && (tu.log2 == 2);
     if (checkTS) { int nb = 0; const int maxp = tu.part + (tu.c_code_all ? 1 : 4); for (int p = tu.part; p < maxp; p++) nb += cu->tskip[0][p]; checkTS = checkTS && (nb > 0); }
   }
-  const int tsv = checkTS ? 2 : 1;
+  const int tsv = checkTS ? 2 : 1, tss = tsv - 1;                /* v / tsv == v >> tss, v % tsv == v & tss */
   /* Without a transform-skip trial nothing is coded between the two components (the bits are counted on the whole tree
    * afterwards), so Cb and Cr of a mode are priced against the same coder state and are independent of each other: both
    * go through one round, ten variants side by side.  With the trial the coder moves on after Cb's winner
@@ -2212,7 +2212,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nvc * n2; i += 64) {
-          const int v = i / n2, p = i - v * n2, b = v / tsv, ts = v % tsv, m = b % 5, comp = comp0 + b / 5;
+          const int v = i / n2, p = i - v * n2, b = (v >> tss), ts = (v & tss), m = b % 5, comp = comp0 + b / 5;
           const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
           const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
           const int32_t t = ts ? ((int32_t)G->p_resi[b * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + b * n2, 0, p);
@@ -2225,7 +2225,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_TIC(t13_);
     FCU_FOR_LANES {                                      /* RDOQ from the mode's coder state (its QT_TRAFO_ROOT) */
       if (lane < nvc) {
-        const int b = lane / tsv, m = b % 5, comp = comp0 + b / 5;
+        const int b = (lane >> tss), m = b % 5, comp = comp0 + b / 5;
         const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
         const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
@@ -2238,18 +2238,18 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {                                      /* levels back to raster order + dequantisation */
       const DeqParams dq = deq_params(log2, P.qp_c);
       for (int i = lane; i < nvc * n2; i += 64) {
-        const int v = i / n2, p = i - v * n2, b = v / tsv, m = b % 5, comp = comp0 + b / 5;
+        const int v = i / n2, p = i - v * n2, b = (v >> tss), m = b % 5, comp = comp0 + b / 5;
         const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
         const int sp = iscan[p];
         const int q = (g_S.vc_abs[v] > 0 && (sp >> 4) <= (g_S.vc_last[v] >> 4)) ? G->p_qscan[sp * nvc + v] : 0;
-        G->p_tmp[(v % tsv) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
+        G->p_tmp[((v & tss)) ? i : v * n2 + tr_index(p, log2)] = dequant1(q, dq);
       }
     }
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nvc * n2; i += 64) {
-          const int v = i / n2, p = i - v * n2, ts = v % tsv;
+          const int v = i / n2, p = i - v * n2, ts = (v & tss);
           if (ts) { const int sft = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (sft - 1))) >> sft; }
           else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, 0, p);
         }
@@ -2258,7 +2258,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nvc * n2; i += 64) {
-          const int v = i / n2, p = i - v * n2, b = v / tsv, ts = v % tsv, y = p >> log2, x = p & (N - 1);
+          const int v = i / n2, p = i - v * n2, b = (v >> tss), ts = (v & tss), y = p >> log2, x = p & (N - 1);
           const uint8_t *org = yuv_plane(&G->org[d], comp0 + b / 5) + tu.cy * 32 + tu.cx;
           int res = 0;
           if (g_S.vc_abs[v] > 0) res = ts ? (int16_t)G->p_tcoef[i] : inv2<decltype(L)::value>(G->p_tcoef + v * n2, 0, p);
