@@ -55,7 +55,7 @@ def test_threshold_of_a_laplacian_with_outliers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gen,w,h", [("mixed", 256, 128), ("smooth", 416, 240), ("mixed", 136, 72), ("smooth", 24, 16), ("textured", 3840, 2160)])
+@pytest.mark.parametrize("gen,w,h", [("mixed", 256, 128), ("smooth", 416, 240), ("mixed", 136, 72), ("textured", 3840, 2160)])
 def test_gpu_prepass_matches_oracle(pkg, gen, w, h):
     frames = [getattr(pkg.synth, gen)(w, h, seed=s)[0] for s in (7, 8)]
     eng = pkg.CuEngine(w, h, max_chains=1)
