@@ -113,3 +113,34 @@ def test_pictures_side_by_side_equal_one_by_one(pkg):
         for p, q in zip(a["rec"], [t.cpu().numpy() for t in b["rec"]]):
             assert np.array_equal(p, q)
     many.close()
+
+
+@pytest.mark.gpu
+def test_command_line_front_end(pkg, tmp_path):
+    """tools/fcu_decide.py end to end on a three-picture 128x64 clip: depth maps and the deblocked .yuv it writes equal
+    what SequenceDecider returns in-process."""
+    import os
+    import subprocess
+    import sys
+    seq = pkg.sequence
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w, h, qp = 128, 64, 30
+    clips = [pkg.synth.mixed(w, h, seed=70 + i) for i in range(3)]
+    src, rec, dep = tmp_path / "in.yuv", tmp_path / "rec.yuv", tmp_path / "depth.npy"
+    with open(src, "wb") as f:
+        for c in clips:
+            seq.write_yuv420(f, c)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fcu_decide.py"), "-i", str(src), "-w", str(w), "-h", str(h),
+                        "-q", str(qp), "--fast", "--period", "3", "--training", "1", "--verifying", "1",
+                        "--rec", str(rec), "--depth", str(dep)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 pictures decided" in r.stdout
+    dec = seq.SequenceDecider(w, h, qp, fast=True, schedule=seq.FastDecisionSchedule(3, 1, 1))
+    depth = np.load(dep)
+    for i, c in enumerate(clips):
+        want = dec.decide(c)
+        assert np.array_equal(depth[i], want["depth"])
+        got = seq.read_yuv420(str(rec), w, h, i)
+        for p, q in zip(got, [t.cpu().numpy() for t in want["rec"]]):
+            assert np.array_equal(p, q)
+    dec.close()
