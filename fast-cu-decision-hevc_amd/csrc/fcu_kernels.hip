@@ -4,8 +4,8 @@
  * Launch geometry: one 64-thread workgroup (= one wavefront) per chain, grid = number of
  * chains advanced by the call.  Chains are dealt round-robin over the 8 XCDs by the
  * dispatcher; a chain's scratch (fcu::Scratch, ~0.7 MB) is touched only by its own wave,
- * so it stays in that XCD's L2 / the Infinity Cache with no cross-XCD traffic.  All CABAC
- * snapshots, reference samples and the SATD staging buffer live in LDS (fcu::Shared, 16 KB).
+ * so it stays in that XCD's L2 / the Infinity Cache with no cross-XCD traffic.  The hot CABAC
+ * coders, reference samples and per-PU mailboxes live in LDS (fcu::Shared + fcu::HotTables, ~10 KB per chain).
  *
  * There is no CPU fallback: every entry point returns FCU_ERR_NO_DEVICE without a GPU.
  */
@@ -46,17 +46,48 @@ struct fcu_ctx {
   Chain *d_chains; Scratch *d_scratch;
   std::vector<Chain> h_chains;
   std::vector<int> h_pos;
-  std::vector<hipEvent_t> ev;      /* start/stop pairs of launches not yet harvested */
+  std::vector<hipEvent_t> ev;      /* start/stop pairs of launches not yet harvested (bounded, see harvest_events) */
   double ms_acc; int launches;
+  /* persistent scratch of fcu_obf_prepass (grown on demand, freed by fcu_destroy) */
+  unsigned *d_hist; size_t hist_cap; int *d_thr; size_t thr_cap;
 };
 
-static char g_err[256] = "";
+/* Launch timing keeps two events per launch until they are read.  A long-running caller that never asks for
+ * fcu_kernel_ms must not grow that list without bound: past FCU_MAX_PENDING_EVENTS pairs the oldest are folded
+ * into the accumulator (they have long completed; hipEventSynchronize on them returns at once) and destroyed. */
+enum { FCU_MAX_PENDING_EVENTS = 64 };
+static void harvest_events(fcu_ctx *c, size_t keep_pairs)
+{
+  while (c->ev.size() > 2 * keep_pairs) {
+    float ms = 0.f;
+    hipEventSynchronize(c->ev[1]);
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->ms_acc += ms; c->launches++; }
+    hipEventDestroy(c->ev[0]); hipEventDestroy(c->ev[1]);
+    c->ev.erase(c->ev.begin(), c->ev.begin() + 2);
+  }
+}
+
+/* one buffer per host thread: a failure text never races with another thread's call */
+static thread_local char g_err[256] = "";
 static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #x, hipGetErrorString(e_)); return FCU_ERR_HIP; } } while (0)
 
 extern "C" {
 
 const char *fcu_last_error(void) { return g_err; }
+
+/* compiler + flags this library was built with (recorded by the build recipe in __graft_entry__.py).  The engine's
+ * correctness depends on `-mllvm -amdgpu-remove-redundant-endcf=false`; tests/test_cabi.py asserts it. */
+#ifndef FCU_BUILD_FLAGS
+#define FCU_BUILD_FLAGS "unrecorded"
+#endif
+#define FCU_STR2(x) #x
+#define FCU_STR(x) FCU_STR2(x)
+const char *fcu_build_info(void)
+{
+  return "hipcc clang " __clang_version__ " HIP " FCU_STR(HIP_VERSION_MAJOR) "." FCU_STR(HIP_VERSION_MINOR) "." FCU_STR(HIP_VERSION_PATCH)
+         " waves_per_eu=" FCU_STR(FCU_WAVES_PER_EU) " flags: " FCU_BUILD_FLAGS;
+}
 
 void fcu_default_frame_params(fcu_frame_params *fp, int qp) { default_frame_params(*fp, qp); }
 
@@ -69,9 +100,12 @@ int fcu_create(const fcu_seq_params *sp, fcu_ctx **out)
   fcu_ctx *c = new fcu_ctx();
   c->sp = *sp; c->n_ctu = ((sp->width + 63) / 64) * ((sp->height + 63) / 64);
   c->ms_acc = 0; c->launches = 0;
+  c->d_chains = nullptr; c->d_scratch = nullptr; c->d_hist = nullptr; c->hist_cap = 0; c->d_thr = nullptr; c->thr_cap = 0;
+  struct Guard { fcu_ctx *c; ~Guard() { if (c) { hipFree(c->d_chains); hipFree(c->d_scratch); delete c; } } } guard{ c };   /* frees on every early return */
   HIPCHK(hipMalloc((void **)&c->d_chains, sizeof(Chain) * (size_t)sp->max_chains));
   HIPCHK(hipMalloc((void **)&c->d_scratch, sizeof(Scratch) * (size_t)sp->max_chains));
   HIPCHK(hipMemset(c->d_chains, 0, sizeof(Chain) * (size_t)sp->max_chains));
+  guard.c = nullptr;
   c->h_chains.resize((size_t)sp->max_chains);
   memset(c->h_chains.data(), 0, sizeof(Chain) * (size_t)sp->max_chains);
   c->h_pos.assign((size_t)sp->max_chains, 0);
@@ -85,7 +119,7 @@ void fcu_destroy(fcu_ctx *c)
   hipSetDevice(c->sp.device);
   hipDeviceSynchronize();
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
-  hipFree(c->d_chains); hipFree(c->d_scratch);
+  hipFree(c->d_chains); hipFree(c->d_scratch); hipFree(c->d_hist); hipFree(c->d_thr);
   delete c;
 }
 
@@ -123,7 +157,10 @@ int fcu_chain_set_range(fcu_ctx *c, int chain, int first_ctu, int n_ctus)
   HIPCHK(hipSetDevice(c->sp.device));
   h.next_ctu = first_ctu; h.end_ctu = first_ctu + n_ctus;
   c->h_pos[(size_t)chain] = first_ctu;
-  HIPCHK(hipMemcpy(&c->d_chains[chain], &h, sizeof(Chain), hipMemcpyHostToDevice));
+  /* only the range: the chain's coder state, verification counters and trial count on the device stay as they are */
+  static_assert(offsetof(Chain, end_ctu) == offsetof(Chain, next_ctu) + sizeof(int), "next_ctu / end_ctu are adjacent");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, next_ctu), &h.next_ctu, 2 * sizeof(int), hipMemcpyHostToDevice));
   return FCU_OK;
 }
 
@@ -140,6 +177,7 @@ int fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, st));
   c->ev.push_back(e0); c->ev.push_back(e1);
+  harvest_events(c, FCU_MAX_PENDING_EVENTS);
   for (int i = first; i < first + n; i++) { int &p = c->h_pos[(size_t)i]; p += ctus; if (p > c->h_chains[(size_t)i].end_ctu) p = c->h_chains[(size_t)i].end_ctu; }
   return FCU_OK;
 }
@@ -157,12 +195,7 @@ double fcu_kernel_ms(fcu_ctx *c, int *launches)
   if (!c) return 0.0;
   hipSetDevice(c->sp.device);
   hipDeviceSynchronize();
-  for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) { c->ms_acc += ms; c->launches++; }
-    hipEventDestroy(c->ev[i]); hipEventDestroy(c->ev[i + 1]);
-  }
-  c->ev.clear();
+  harvest_events(c, 0);
   const int n = c->launches; const double avg = n ? c->ms_acc / n : 0.0;
   if (launches) *launches = n;
   c->ms_acc = 0; c->launches = 0;
@@ -275,11 +308,13 @@ int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev
   hipStream_t st = (hipStream_t)hip_stream;
   const int w = c->sp.width, h = c->sp.height, nblk = (w / 4) * (h / 4);
   const size_t frame_bytes = (size_t)w * h, hist_n = (size_t)n_frames * 15 * OBF_HB;
-  unsigned *d_hist = nullptr; int *d_thr = nullptr;
-  HIPCHK(hipMalloc((void **)&d_hist, hist_n * sizeof(unsigned)));
-  HIPCHK(hipMalloc((void **)&d_thr, (size_t)n_frames * 16 * sizeof(int)));
+  /* histogram / threshold buffers belong to the context and only grow: no allocation in the steady state */
+  if (c->hist_cap < hist_n) { hipFree(c->d_hist); c->d_hist = nullptr; c->hist_cap = 0; HIPCHK(hipMalloc((void **)&c->d_hist, hist_n * sizeof(unsigned))); c->hist_cap = hist_n; }
+  if (c->thr_cap < (size_t)n_frames * 16) { hipFree(c->d_thr); c->d_thr = nullptr; c->thr_cap = 0; HIPCHK(hipMalloc((void **)&c->d_thr, (size_t)n_frames * 16 * sizeof(int))); c->thr_cap = (size_t)n_frames * 16; }
+  unsigned *d_hist = c->d_hist; int *d_thr = c->d_thr;
   HIPCHK(hipMemsetAsync(d_hist, 0, hist_n * sizeof(unsigned), st));
-  hipEvent_t e[4];
+  hipEvent_t e[4] = { nullptr, nullptr, nullptr, nullptr };
+  struct EventGuard { hipEvent_t *e; ~EventGuard() { for (int i = 0; i < 4; i++) if (e[i]) hipEventDestroy(e[i]); } } guard{ e };
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&e[i]));
   const int ngrp = (((w / 4) + 3) / 4) * (h / 4);               /* groups of four blocks along a row */
   const dim3 grid((unsigned)((ngrp + OBF_THREADS * OBF_GROUPS_PER_THREAD - 1) / (OBF_THREADS * OBF_GROUPS_PER_THREAD)), (unsigned)n_frames);
@@ -307,7 +342,7 @@ int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev
     for (auto &th : pool) th.join();
   }
   for (size_t k = 0; k < (size_t)n_frames * 15; k++)           /* the clamp bin is unreachable for 8-bit sources (|coef/8| <= 4080) */
-    if (hist[k * OBF_HB + OBF_HB - 1]) { hipFree(d_hist); hipFree(d_thr); return fail(FCU_ERR_ARG, "fcu_obf_prepass: amplitude beyond the histogram (not an 8-bit plane?)"); }
+    if (hist[k * OBF_HB + OBF_HB - 1]) { return fail(FCU_ERR_ARG, "fcu_obf_prepass: amplitude beyond the histogram (not an 8-bit plane?)"); }
   HIPCHK(hipMemcpyAsync(d_thr, thr.data(), thr.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(e[2], st));
   hipLaunchKernelGGL(obf_count, grid, dim3(OBF_THREADS), 0, st, dev_y, w, h, frame_bytes, d_thr, dev_obf);
@@ -316,8 +351,6 @@ int fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev
   HIPCHK(hipStreamSynchronize(st));
   if (kernel_ms2) { hipEventElapsedTime(&kernel_ms2[0], e[0], e[1]); hipEventElapsedTime(&kernel_ms2[1], e[2], e[3]); }
   if (host_yc) memcpy(host_yc, yc.data(), yc.size() * sizeof(double));
-  for (int i = 0; i < 4; i++) hipEventDestroy(e[i]);
-  hipFree(d_hist); hipFree(d_thr);
   return FCU_OK;
 }
 

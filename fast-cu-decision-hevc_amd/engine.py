@@ -63,7 +63,8 @@ class VerifyCounts(C.Structure):
 EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctus", "fcu_chain_begin",
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
-           "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock"]
+           "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
+           "fcu_build_info"]
 
 
 def lib_path():
@@ -100,6 +101,7 @@ def load_lib():
     lib.fcu_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.fcu_debug_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.fcu_last_error.restype = C.c_char_p
+    lib.fcu_build_info.restype = C.c_char_p
     lib.fcu_chain_set_decision.argtypes = [C.c_void_p, C.c_int, C.POINTER(DecisionParams)]
     lib.fcu_get_verify_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VerifyCounts)]
     lib.fcu_decision_switch.restype = None
@@ -188,7 +190,10 @@ class CuEngine:
         fp = FrameParams()
         self.lib.fcu_default_frame_params(C.byref(fp), qp)
         fp.slice_ctus = slice_ctus
+        known = {n for n, _ in FrameParams._fields_}
         for k, v in flags.items():
+            if k not in known:                                  # a misspelt tool flag must not be dropped silently
+                raise TypeError(f"init_chain: unknown frame parameter {k!r} (fcu_frame_params has {sorted(known)})")
             setattr(fp, k, v)
         self._chk(self.lib.fcu_chain_begin(self.h, chain, C.byref(fp), *[p.data_ptr() for p in planes],
                                            *[p.data_ptr() for p in rec], out.data_ptr()), "fcu_chain_begin")

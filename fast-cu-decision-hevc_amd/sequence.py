@@ -79,11 +79,16 @@ class SequenceDecider:
     (plain HM RDO); `fast=True` runs the fork's Training / Verifying / Testing cycle with its default (Naive) control."""
 
     def __init__(self, width, height, qp, slice_ctus=None, fast=True, deblock=True, device=0, schedule=None, in_flight=1, **flags):
+        """slice_ctus: CTUs per slice (HM's SliceMode 1 / SliceArgument).  None = one slice per picture, which is the
+        reference's default (SliceMode 0, TAppEncCfg.cpp:838) and what `encoder_intra_main.cfg` encodes; a smaller value
+        (e.g. the picture width in CTUs for one slice per CTU row) is a DIFFERENT encoder configuration -- the slices then
+        run as concurrent chains, but every slice start cuts the intra neighbourhood and resets CABAC."""
         self.width, self.height, self.qp, self.fast, self.do_deblock, self.flags = width, height, qp, fast, deblock, flags
         self.in_flight = max(1, in_flight)
         w_ctu = (width + 63) // 64
-        self.slice_ctus = slice_ctus if slice_ctus else w_ctu          # one CTU row per slice: rows decide concurrently
         n_ctu = w_ctu * ((height + 63) // 64)
+        self.slice_ctus = slice_ctus if slice_ctus else n_ctu
+        self.slice_mode = "SliceMode 0 (one slice per picture)" if self.slice_ctus >= n_ctu else f"SliceMode 1, SliceArgument {self.slice_ctus}"
         self.n_slices = (n_ctu + self.slice_ctus - 1) // self.slice_ctus
         self.eng = _engine.CuEngine(width, height, max_chains=self.n_slices * self.in_flight, device=device)
         self.schedule = schedule or FastDecisionSchedule()

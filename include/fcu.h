@@ -152,8 +152,11 @@ int  fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uin
                  int beta_offset_div2, int tc_offset_div2, float *kernel_ms2, void *hip_stream);
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);
-/* text of the last failure (one process-wide buffer: calls on one context are not re-entrant; use one context per host thread) */
+/* text of the calling thread's last failure (one buffer per host thread) */
 const char *fcu_last_error(void);
+/* compiler version and the exact flags libfcu.so was built with.  The engine relies on
+ * `-mllvm -amdgpu-remove-redundant-endcf=false`: a build without it is refused by tests/test_cabi.py. */
+const char *fcu_build_info(void);
 
 #ifdef __cplusplus
 }

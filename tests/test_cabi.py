@@ -24,6 +24,28 @@ def test_header_symbols_are_exported(built, pkg):
     assert sorted(pkg.engine.EXPORTS) == syms
 
 
+def test_build_line_carries_the_exec_mask_workaround(built, pkg):
+    """The shipped engine is only correct when built with `-mllvm -amdgpu-remove-redundant-endcf=false` (DESIGN.md 2:
+    without it a VGPR reload lands under a partial exec mask -> stale lanes -> GPU memory fault).  The library
+    reports its own build line; a build that lost the flag, or whose compiler is not the recorded one, fails here
+    on the CPU before anything reaches a GPU."""
+    import __graft_entry__ as g
+    lib = C.CDLL(pkg.lib_path())
+    lib.fcu_build_info.restype = C.c_char_p
+    info = lib.fcu_build_info().decode()
+    assert g.REQUIRED_FLAG in info and "-mllvm" in info, info
+    assert "-ffp-contract=off" in info and "--offload-arch=gfx950" in info, info
+    assert "clang" in info and "HIP" in info, info
+
+
+def test_unknown_frame_parameter_is_rejected(pkg):
+    """init_chain must not drop a misspelt tool flag (the oracle says strong_smoothing, the ABI strong_intra_smoothing)."""
+    known = {n for n, _ in pkg.engine.FrameParams._fields_}
+    assert "strong_intra_smoothing" in known and "strong_smoothing" not in known
+    src = open(os.path.join(ROOT, "fast-cu-decision-hevc_amd", "engine.py")).read()
+    assert "unknown frame parameter" in src
+
+
 def test_struct_layouts_match_between_binding_and_oracle(built, pkg):
     import hmo_py
     assert C.sizeof(pkg.engine.CtuOut) == C.sizeof(hmo_py.Ctu)

@@ -58,7 +58,8 @@ def test_sequence_decider_matches_oracle_over_a_period(pkg, tmp_path):
     with open(path, "wb") as f:
         for i in range(n):
             seq.write_yuv420(f, pkg.synth.smooth(w, h, seed=40 + i // 3))      # content changes every third picture
-    dec = seq.SequenceDecider(w, h, qp, fast=True, schedule=seq.FastDecisionSchedule(period=5, n_training=1, n_verifying=1))
+    dec = seq.SequenceDecider(w, h, qp, slice_ctus=3, fast=True, schedule=seq.FastDecisionSchedule(period=5, n_training=1, n_verifying=1))
+    assert dec.slice_mode.startswith("SliceMode 1") and dec.n_slices == 2
     ref_sched = seq.FastDecisionSchedule(period=5, n_training=1, n_verifying=1, decision_switch=hmo_py.decision_switch)
     states = []
     for i in range(n):

@@ -7,6 +7,11 @@ encoder_intra_main.cfg` that this repository replaces (no bitstream is written).
 --fast runs the fork's Training / Verifying / Testing cycle (period / training / verifying pictures as in the reference:
 60 / 2 / 1); without it every picture gets the exhaustive HM search.  --rec receives the deblocked reconstruction,
 --depth an array [pictures, CTUs, 256] of CU depths per 4x4 partition in z-order (TComDataCU::getDepth).
+
+Slices: by default a picture is ONE slice, as in the reference's configuration (SliceMode 0) -- pictures side by side
+(--in-flight) are then the source of parallelism.  --slice-ctus N / --row-slices select HM's SliceMode 1 with N CTUs (one
+CTU row) per slice: a different encoder configuration (neighbourhood cut and CABAC reset at every slice start), whose
+slices are decided concurrently.  The slice mode is echoed on every picture line.
 """
 import argparse
 import os
@@ -33,13 +38,16 @@ def main():
     ap.add_argument("--verifying", type=int, default=1)
     ap.add_argument("--no-deblock", action="store_true")
     ap.add_argument("--in-flight", type=int, default=16, help="pictures decided side by side when the schedule allows it")
+    ap.add_argument("--slice-ctus", type=int, default=0, help="SliceMode 1: CTUs per slice (default: one slice per picture)")
+    ap.add_argument("--row-slices", action="store_true", help="SliceMode 1 with one CTU row per slice")
     ap.add_argument("--rec")
     ap.add_argument("--depth")
     args = ap.parse_args()
     import __graft_entry__ as g
     pkg = g.load_package()
     seq = pkg.sequence
-    dec = seq.SequenceDecider(args.width, args.height, args.qp, fast=args.fast, deblock=not args.no_deblock, in_flight=args.in_flight,
+    slice_ctus = (args.width + 63) // 64 if args.row_slices else (args.slice_ctus or None)
+    dec = seq.SequenceDecider(args.width, args.height, args.qp, slice_ctus=slice_ctus, fast=args.fast, deblock=not args.no_deblock, in_flight=args.in_flight,
                               schedule=seq.FastDecisionSchedule(args.period, args.training, args.verifying))
     names = {seq.TRAINING: "training", seq.VERIFYING: "verifying", seq.TESTING: "testing"}
     rec_f = open(args.rec, "wb") if args.rec else None
@@ -66,7 +74,7 @@ def main():
                 ssd = float((d * d).sum())
                 psnr.append(999.99 if ssd == 0 else 10.0 * np.log10(255.0 * 255.0 * d.size / ssd))
             hist = np.bincount(r["depth"].ravel(), minlength=4)
-            print(f"POC {r['poc']:4d} {names[r['state']]:9s} skip2Nx2N={r['sw_skip'].tolist()} terminate={r['sw_term'].tolist()} "
+            print(f"POC {r['poc']:4d} {names[r['state']]:9s} [{dec.slice_mode}] skip2Nx2N={r['sw_skip'].tolist()} terminate={r['sw_term'].tolist()} "
                   f"partitions at depth 0..3 = {hist.tolist()}  TU trials {r['tu_trials']}  "
                   f"PSNR Y {psnr[0]:.4f} U {psnr[1]:.4f} V {psnr[2]:.4f} dB", flush=True)
             if rec_f:
