@@ -116,12 +116,17 @@ namespace fcu {
 
 /* ---- constants ------------------------------------------------------------------------ */
 enum { CTU = 64, MAXDEPTH = 3, NPART = 256, LOG2_MAXTU = 5, LOG2_MINTU = 2, TU_MAXDEPTH_INTRA = 3 };
-enum { SIZE_2Nx2N = 0, SIZE_NxN = 3, SIZE_NONE = 8, MODE_INTRA = 1, MODE_NONE = 2 };
+enum { SIZE_2Nx2N = 0, SIZE_2NxN = 1, SIZE_Nx2N = 2, SIZE_NxN = 3, SIZE_NONE = 8, MODE_INTER = 0, MODE_INTRA = 1, MODE_NONE = 2 };
+enum { SLICE_I = 0, SLICE_P = 1 };
 enum { PLANAR = 0, DC = 1, HOR = 10, VER = 26, DM_CHROMA = 36 };
 /* context layout (counts: TLibCommon/ContextTables.h:49-161) */
 enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5, CTX_CBF_LUMA = 6, CTX_CBF_CHROMA = 11,
        CTX_SUBDIV = 16, CTX_SIGCG = 19, CTX_SIG = 23, CTX_LASTX = 67, CTX_LASTY = 97, CTX_ONE = 127, CTX_ABS = 151,
-       CTX_TSKIP = 157, NCTX = 160 };
+       CTX_TSKIP = 157, NCTX_INTRA = 160,
+       /* inter syntax of P slices, appended: skip flag (3), merge flag, merge index, pred mode, part-size contexts 1..3,
+        * mvd (2), ref idx (2), mvp idx, rqt root cbf, pad */
+       CTX_SKIP = 160, CTX_MERGE_FLAG = 163, CTX_MERGE_IDX = 164, CTX_PRED_MODE = 165, CTX_PARTSIZE1 = 166, CTX_MVD = 169,
+       CTX_REF = 171, CTX_MVP_IDX = 173, CTX_ROOT_CBF = 174, NCTX = 176 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
 enum { MAXVC = 20, MAXLC = 16, POOL = 5120 };   /* MAXVC candidate variants of a batch, MAXLC lane-private coders (the bit count runs in rounds) */
 /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
@@ -131,7 +136,7 @@ enum { MAXVC = 20, MAXLC = 16, POOL = 5120 };   /* MAXVC candidate variants of a
 struct Cabac { uint8_t ctx[NCTX]; uint64_t frac; uint32_t bins; uint32_t pad_; };
 
 struct Params {
-  int width, height, qp, qp_c, slice_ctus;
+  int width, height, qp, qp_c, slice_ctus, slice_type;
   int transform_skip, ts_fast, sign_hiding, strong_smoothing;
   double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
   double err_scale[2][4];     /* [luma/chroma][log2-2]   setErrScaleCoeff, TComTrQuant.cpp:3018-3040 */
@@ -224,7 +229,7 @@ struct Shared {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
     int uni[8];                                                       /* chroma leaf: transform-skip choice per mode */
   };
-  uint32_t est[NCTX * 2];                            /* estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
+  uint32_t est[NCTX_INTRA * 2];                            /* estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
   uint8_t vc_slot[MAXVC];                           /* lane coder that holds a variant's state after the bit count */
   int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
   int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
@@ -314,11 +319,11 @@ FCU_DEV int tu_nparts_c(const TU &t) { return t.c_code_all ? t.nparts : t.nparts
 /* ======================================================================================== */
 /* CABAC bit counter -- per-lane callable (TEncBinCoderCABACCounter.cpp:59-136)              */
 /* ======================================================================================== */
-FCU_DEV void cab_init(Cabac *c, int qp)            /* ContextModel::init, ContextModel.cpp:56-65 */
+FCU_DEV void cab_init(Cabac *c, int qp, int sliceType)   /* ContextModel::init, ContextModel.cpp:56-65; TEncSbac::resetEntropy :106-156 */
 {
   if (qp < 0) qp = 0; if (qp > 51) qp = 51;
   for (int i = 0; i < NCTX; i++) {
-    int iv = k_ctx_init_I[i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
+    int iv = sliceType == SLICE_P ? k_ctx_init_P[i] : k_ctx_init_I[i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
     int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
     int mps = st >= 64;
     c->ctx[i] = (uint8_t)(((mps ? (st - 64) : (63 - st)) << 1) + mps);
@@ -345,7 +350,7 @@ FCU_DEV uint32_t cab_bits(int cid) { return (uint32_t)(FCU_CB.frac >> 15); }
 FCU_DEV int ctx_bits(int cid, int ctx, int bin) { return (int)(g_hot.bin[FCU_CB.ctx[ctx] * 2 + bin] >> 8); }
 /* TEncSbac::estBit: the costs of both bins of every context of coder `cid`, one LDS word each; called by all lanes
  * in the phase before RDOQ (the contexts are frozen while RDOQ runs) */
-FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX * 2; i += 64) g_S.est[i] = g_hot.bin[FCU_CB.ctx[i >> 1] * 2 + (i & 1)] >> 8; }
+FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX_INTRA * 2; i += 64) g_S.est[i] = g_hot.bin[FCU_CB.ctx[i >> 1] * 2 + (i & 1)] >> 8; }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -2612,11 +2617,13 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
   E.cur_ctu = ctuRsAddr; E.slice_start = sliceStart;
   fcu_ctu_out *out = &C->out[ctuRsAddr];
   const int x = (ctuRsAddr % C->w_ctu) * CTU, y = (ctuRsAddr / C->w_ctu) * CTU;
-  FCU_SERIAL { g_S.env = E; if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
+  FCU_SERIAL { g_S.env = E; if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp, P.slice_type); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
   FCU_FOR_LANES {                                            /* TComDataCU::initCtu defaults, TComDataCU.cpp:474-560 */
     for (int i = lane; i < NPART; i += 64) {
       out->depth[i] = 0; out->width[i] = CTU; out->height[i] = CTU; out->skip[i] = 0; out->part_size[i] = SIZE_NONE; out->pred_mode[i] = MODE_NONE;
       out->tq_bypass[i] = 0; out->qp[i] = (int8_t)P.qp; out->chroma_qp_adj[i] = 0; out->tr_idx[i] = 0; out->ipcm[i] = 0;
+      out->merge_flag[i] = 0; out->merge_idx[i] = 0; out->inter_dir[i] = 0; out->mvp_idx[i] = -1; out->ref_idx[i] = -1;   /* clearMvField: NOT_VALID */
+      out->mv[i][0] = out->mv[i][1] = 0; out->mvd[i][0] = out->mvd[i][1] = 0;
       for (int c = 0; c < 3; c++) { out->tskip[c][i] = 0; out->cbf[c][i] = 0; }
       out->intra_dir[0][i] = DC; out->intra_dir[1][i] = 0;
     }

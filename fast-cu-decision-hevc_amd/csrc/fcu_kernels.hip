@@ -239,7 +239,7 @@ int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bit
   HIPCHK(hipDeviceSynchronize());
   Chain h;
   HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
-  memcpy(ctx160, h.state.ctx, NCTX);
+  memcpy(ctx160, h.state.ctx, NCTX_INTRA);
   *frac_bits = h.state.frac;
   return FCU_OK;
 }
@@ -298,6 +298,15 @@ int fcu_chains_per_cu(void)
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fcu_ctu_engine, 64, 0) != hipSuccess) return -1;
   return n;
+}
+
+/* the host step of the pre-pass on its own: Yc of one frequency from its amplitude histogram (pure host arithmetic, no GPU) */
+double fcu_tcm_threshold(const unsigned *hist, int hist_len, int n_samples)
+{
+  if (!hist || hist_len <= 0 || n_samples <= 0) return 0.0;
+  std::vector<unsigned> h((size_t)OBF_HB, 0u);
+  for (int i = 0; i < hist_len && i < OBF_HB; i++) h[(size_t)i] = hist[i];
+  return tcm_threshold(h.data(), n_samples);
 }
 
 /* ---- fork pre-pass: OBF maps of n luma planes ------------------------------------------------------------ */

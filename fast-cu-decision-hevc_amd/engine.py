@@ -40,6 +40,9 @@ class CtuOut(C.Structure):
                 ("tq_bypass", C.c_uint8 * NPART), ("qp", C.c_int8 * NPART), ("chroma_qp_adj", C.c_uint8 * NPART),
                 ("tr_idx", C.c_uint8 * NPART), ("tskip", (C.c_uint8 * NPART) * 3), ("cbf", (C.c_uint8 * NPART) * 3),
                 ("intra_dir", (C.c_uint8 * NPART) * 2), ("ipcm", C.c_uint8 * NPART),
+                ("merge_flag", C.c_uint8 * NPART), ("merge_idx", C.c_uint8 * NPART), ("inter_dir", C.c_uint8 * NPART),
+                ("mvp_idx", C.c_int8 * NPART), ("ref_idx", C.c_int8 * NPART),
+                ("mv", (C.c_int16 * 2) * NPART), ("mvd", (C.c_int16 * 2) * NPART),
                 ("coeff_y", C.c_int32 * 4096), ("coeff_cb", C.c_int32 * 1024), ("coeff_cr", C.c_int32 * 1024),
                 ("total_cost", C.c_double), ("total_dist", C.c_uint32), ("total_bits", C.c_uint32),
                 ("total_bins", C.c_uint32)]
@@ -64,7 +67,7 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
-           "fcu_build_info"]
+           "fcu_build_info", "fcu_tcm_threshold"]
 
 
 def lib_path():
@@ -102,6 +105,8 @@ def load_lib():
     lib.fcu_debug_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.fcu_last_error.restype = C.c_char_p
     lib.fcu_build_info.restype = C.c_char_p
+    lib.fcu_tcm_threshold.restype = C.c_double
+    lib.fcu_tcm_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fcu_chain_set_decision.argtypes = [C.c_void_p, C.c_int, C.POINTER(DecisionParams)]
     lib.fcu_get_verify_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VerifyCounts)]
     lib.fcu_decision_switch.restype = None

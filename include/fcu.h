@@ -56,6 +56,11 @@ typedef struct fcu_ctu_out {
   uint8_t  cbf[3][FCU_NPART];                                       /* m_puhCbf (bit t = depth t) */
   uint8_t  intra_dir[2][FCU_NPART];                                 /* m_puhIntraDir           */
   uint8_t  ipcm[FCU_NPART];                                         /* m_pbIPCMFlag            */
+  /* inter prediction data, reference picture list 0 (P slices; list 1 does not exist in the configurations built) */
+  uint8_t  merge_flag[FCU_NPART], merge_idx[FCU_NPART];             /* m_pbMergeFlag, m_puhMergeIndex */
+  uint8_t  inter_dir[FCU_NPART];                                    /* m_puhInterDir (1 = list 0) */
+  int8_t   mvp_idx[FCU_NPART], ref_idx[FCU_NPART];                  /* m_apiMVPIdx[0], m_acCUMvField[0] refIdx (-1 = none) */
+  int16_t  mv[FCU_NPART][2], mvd[FCU_NPART][2];                     /* m_acCUMvField[0] mv / mvd, quarter samples, [hor, ver] */
   int32_t  coeff_y[4096], coeff_cb[1024], coeff_cr[1024];           /* m_pcTrCoeff             */
   double   total_cost;                                              /* m_dTotalCost            */
   uint32_t total_dist, total_bits, total_bins;                      /* m_uiTotal*              */
@@ -115,6 +120,10 @@ int  fcu_debug_counters(fcu_ctx *c, int chain, unsigned long long *out17);
  * the histogram and the counting kernel.  Synchronous (the threshold fit runs on the host between the kernels). */
 int  fcu_obf_prepass(fcu_ctx *c, int n_frames, const uint8_t *dev_y, int16_t *dev_obf, double *host_yc,
                      float *kernel_ms2, void *hip_stream);
+/* The host step of fcu_obf_prepass on its own: TCMprocessOneSequence (TEncSlice.cpp:343-392) on the histogram of
+ * |coefficient / 8| of one frequency (hist[a] = samples of amplitude a, n_samples in total); returns the threshold Yc.
+ * Pure host arithmetic (doubles + libm, as the reference); needs no GPU. */
+double fcu_tcm_threshold(const unsigned *hist, int hist_len, int n_samples);
 /* ---- the fork's fast CU-size decision (its default control: Naive model on the N_OBF feature, YSGlobalControl,
  * tools_YS.cpp:4-58).  A chain starts in FCU_TRAINING (exhaustive RDO).  FCU_VERIFYING is exhaustive too and counts,
  * per depth, how the Naive label ("split" when the CU holds an outlier block, "do not split" when it holds none)

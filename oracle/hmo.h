@@ -34,6 +34,8 @@ extern "C" {
 
 /* enums as TypeDef.h:470-489 */
 #define HMO_SIZE_2Nx2N   0
+#define HMO_SIZE_2NxN    1
+#define HMO_SIZE_Nx2N    2
 #define HMO_SIZE_NxN     3
 #define HMO_SIZE_NONE    8      /* NUMBER_OF_PART_SIZES */
 #define HMO_MODE_INTER   0
@@ -61,8 +63,21 @@ enum {
   HMO_CTX_ONE        = 127,  /* 16 luma + 8 chroma */
   HMO_CTX_ABS        = 151,  /* 4 luma + 2 chroma */
   HMO_CTX_TSKIP      = 157,  /* 1 luma + 1 chroma */
-  HMO_NCTX           = 160
+  HMO_NCTX_INTRA     = 160,  /* the contexts an I slice touches (+1 pad) */
+  /* inter syntax (P slices), appended so that the all-intra layout above stays what it was */
+  HMO_CTX_SKIP       = 160,  /* 3  cu_skip_flag                        */
+  HMO_CTX_MERGE_FLAG = 163,  /* 1                                      */
+  HMO_CTX_MERGE_IDX  = 164,  /* 1                                      */
+  HMO_CTX_PRED_MODE  = 165,  /* 1                                      */
+  HMO_CTX_PARTSIZE1  = 166,  /* 3  part_mode contexts 1..3 (0 = HMO_CTX_PARTSIZE) */
+  HMO_CTX_MVD        = 169,  /* 2  abs_mvd_greater0 / greater1         */
+  HMO_CTX_REF        = 171,  /* 2  ref_idx                             */
+  HMO_CTX_MVP_IDX    = 173,  /* 1                                      */
+  HMO_CTX_ROOT_CBF   = 174,  /* 1  rqt_root_cbf                        */
+  HMO_NCTX           = 176   /* + 1 pad */
 };
+#define HMO_SLICE_I 0
+#define HMO_SLICE_P 1
 
 /* coder state that HM copies with TEncSbac::load/store (TEncSbac.cpp:397-426,
  * TEncBinCoderCABAC.cpp:148-159): all context states + the fractional bit counter. */
@@ -89,6 +104,16 @@ typedef struct {
   double chroma_weight;         /* m_distortionWeight[Cb/Cr]         TEncSlice.cpp:510     */
   double rdoq_lambda[3];        /* TComTrQuant::m_lambdas            TEncSlice.cpp:512     */
   int    qp_c;                  /* chroma QP (g_aucChromaScale)                             */
+  /* ---- inter (P slices, BASELINE configs[4]); all 0 for an I slice ---- */
+  int slice_type;               /* HMO_SLICE_I / HMO_SLICE_P */
+  int search_range;             /* SearchRange (integer samples) */
+  int fast_search;              /* FastSearch: 0 = full search (xPatternSearch), 1 = TZ search */
+  int fast_enc;                 /* FEN (getUseFastEnc): sub-sampled SAD in the integer search */
+  int had_me;                   /* HadamardME: SATD in the fractional search / merge estimation */
+  int fdm;                      /* FDM (getUseFastDecisionForMerge) */
+  int max_merge_cand;           /* MaxNumMergeCand (5) */
+  double lambda_override;       /* > 0: slice lambda given by the caller (P-slice QP factor, TEncSlice.cpp:686-706) */
+  unsigned lambda_motion_sad, lambda_motion_sse;   /* m_uiLambdaMotionSAD / SSE, TComRdCost.cpp:194-219 */
 } HmoParams;
 
 /* Per-CTU decisions, TComDataCU layout (TComDataCU.h:72-164).  One entry
@@ -105,6 +130,10 @@ typedef struct {
   uint8_t  cbf[3][HMO_NPART];
   uint8_t  intra_dir[2][HMO_NPART];
   uint8_t  ipcm[HMO_NPART];
+  /* inter (list 0 only: P slices) -- m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_apiMVPIdx[0], m_acCUMvField[0] */
+  uint8_t  merge_flag[HMO_NPART], merge_idx[HMO_NPART], inter_dir[HMO_NPART];
+  int8_t   mvp_idx[HMO_NPART], ref_idx[HMO_NPART];
+  int16_t  mv[HMO_NPART][2], mvd[HMO_NPART][2];        /* quarter-sample units, [hor, ver] */
   int32_t  coeff_y[HMO_CTU * HMO_CTU];          /* TU-contiguous, offset = absPartIdx*16 */
   int32_t  coeff_cb[HMO_CTU * HMO_CTU / 4];
   int32_t  coeff_cr[HMO_CTU * HMO_CTU / 4];
@@ -156,7 +185,8 @@ void    hmo_intra_pred(const uint8_t *ref, const uint8_t *refFilt, int log2, int
                        uint8_t *dst, int dstStride);
 void    hmo_filter_ref(const uint8_t *ref, uint8_t *out, int n, int strong);
 int     hmo_use_filtered_ref(int mode, int log2, int isLuma);
-void    hmo_cabac_init(HmoCabac *c, int qp);
+void    hmo_cabac_init(HmoCabac *c, int qp);                 /* I-slice tables */
+void    hmo_cabac_init_st(HmoCabac *c, int qp, int slice_type);
 const int16_t *hmo_dct_matrix(int log2);   /* N*N, row-major */
 const uint16_t *hmo_scan(int scanType, int log2);
 const uint8_t *hmo_zscan_to_raster(void);

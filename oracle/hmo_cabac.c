@@ -6,13 +6,15 @@
 #include <string.h>
 
 /* ContextModel::init, ContextModel.cpp:56-65 ; TEncSbac::resetEntropy, TEncSbac.cpp:106-156 */
-void hmo_cabac_init(HmoCabac *c, int qp)
+void hmo_cabac_init(HmoCabac *c, int qp) { hmo_cabac_init_st(c, qp, HMO_SLICE_I); }
+void hmo_cabac_init_st(HmoCabac *c, int qp, int slice_type)
 {
   hmo_init_tables();
   if (qp < 0) qp = 0;
   if (qp > 51) qp = 51;
+  const uint8_t *tab = slice_type == HMO_SLICE_P ? hmo_ctx_init_P : hmo_ctx_init_I;   /* initType: cabac_init_flag 0 */
   for (int i = 0; i < HMO_NCTX; i++) {
-    int iv = hmo_ctx_init_I[i];
+    int iv = tab[i];
     int slope = (iv >> 4) * 5 - 45;
     int offset = ((iv & 15) << 3) - 16;
     int st = ((slope * qp) >> 4) + offset;

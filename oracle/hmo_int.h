@@ -18,7 +18,7 @@ extern const int hmo_ang_table[9], hmo_inv_ang_table[9];
 extern const uint8_t hmo_intra_filter_thr[5], hmo_rd_mode_num[5];
 extern const uint8_t hmo_next_mps[128], hmo_next_lps[128];
 extern const int32_t hmo_entropy_bits[128];
-extern const uint8_t hmo_ctx_init_I[HMO_NCTX];
+extern const uint8_t hmo_ctx_init_I[HMO_NCTX], hmo_ctx_init_P[HMO_NCTX];
 void hmo_init_tables(void);
 
 /* Working copy of one CU's decisions (the per-depth TComDataCU best/temp objects,
@@ -34,6 +34,9 @@ typedef struct {
   uint8_t  tr_idx[HMO_NPART];
   uint8_t  tskip[3][HMO_NPART], cbf[3][HMO_NPART];
   uint8_t  intra_dir[2][HMO_NPART];
+  uint8_t  skip[HMO_NPART], merge_flag[HMO_NPART], merge_idx[HMO_NPART], inter_dir[HMO_NPART];
+  int8_t   mvp_idx[HMO_NPART], ref_idx[HMO_NPART];
+  int16_t  mv[HMO_NPART][2], mvd[HMO_NPART][2];
   int32_t  coef[3][HMO_CTU * HMO_CTU];   /* chroma uses the first quarter */
 } HmoCU;
 
@@ -95,7 +98,14 @@ struct HmoEnc {
   double ver[4][6];                  /* g_iVerResult[depth][Naive][ResultType] */
   /* statistics for tests */
   uint64_t n_tu_trials, n_rmd;
+  uint32_t last_luma_dist;
+  /* test hook: called around every CU candidate so that a test can show the same state to the reference's own
+   * search code (oracle/ref/make_golden_search.py) or compare with what it returned (tests/test_golden_search.py) */
+  void (*trace)(void *user, int event, int depth, int arg);
+  void *trace_user;
 };
+/* trace events: candidate about to be searched / searched (its results sit in temp[depth], reco_temp[depth], slot[depth][CI_TEMP_BEST]) */
+enum { HMO_EV_INTRA_BEGIN = 0, HMO_EV_INTRA_END = 1, HMO_EV_INTER_BEGIN = 2, HMO_EV_INTER_END = 3, HMO_EV_MERGE_BEGIN = 4, HMO_EV_MERGE_END = 5 };
 
 /* ---- hmo_cabac.c */
 static inline void hmo_cabac_copy(HmoCabac *d, const HmoCabac *s) { *d = *s; }

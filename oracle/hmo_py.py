@@ -13,7 +13,10 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("qp", C.c_int), ("slice_ctus", C.c_int),
                 ("transform_skip", C.c_int), ("transform_skip_fast", C.c_int), ("sign_hiding", C.c_int),
                 ("strong_smoothing", C.c_int), ("lambda_", C.c_double), ("sqrt_lambda", C.c_double),
-                ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int)]
+                ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
+                ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
+                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("lambda_override", C.c_double),
+                ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint)]
 
 
 class Ctu(C.Structure):
@@ -22,13 +25,42 @@ class Ctu(C.Structure):
                 ("tq_bypass", C.c_uint8 * NPART), ("qp", C.c_int8 * NPART), ("chroma_qp_adj", C.c_uint8 * NPART),
                 ("tr_idx", C.c_uint8 * NPART), ("tskip", (C.c_uint8 * NPART) * 3), ("cbf", (C.c_uint8 * NPART) * 3),
                 ("intra_dir", (C.c_uint8 * NPART) * 2), ("ipcm", C.c_uint8 * NPART),
+                ("merge_flag", C.c_uint8 * NPART), ("merge_idx", C.c_uint8 * NPART), ("inter_dir", C.c_uint8 * NPART),
+                ("mvp_idx", C.c_int8 * NPART), ("ref_idx", C.c_int8 * NPART),
+                ("mv", (C.c_int16 * 2) * NPART), ("mvd", (C.c_int16 * 2) * NPART),
                 ("coeff_y", C.c_int32 * 4096), ("coeff_cb", C.c_int32 * 1024), ("coeff_cr", C.c_int32 * 1024),
                 ("total_cost", C.c_double), ("total_dist", C.c_uint32), ("total_bits", C.c_uint32),
                 ("total_bins", C.c_uint32)]
 
 
+NCTX = 176                                   # HMO_NCTX: 160 intra contexts + the inter syntax (hmo.h)
+
+
 class Cabac(C.Structure):
-    _fields_ = [("ctx", C.c_uint8 * 160), ("frac", C.c_uint64)]
+    _fields_ = [("ctx", C.c_uint8 * NCTX), ("frac", C.c_uint64)]
+
+
+class CU(C.Structure):
+    """HmoCU (hmo_int.h): a per-depth working CU, arrays relative to the CU's first partition."""
+    _fields_ = [("depth_cu", C.c_int), ("x", C.c_int), ("y", C.c_int), ("zidx", C.c_int), ("nparts", C.c_int),
+                ("cost", C.c_double), ("dist", C.c_uint32), ("bits", C.c_uint32), ("bins", C.c_uint32),
+                ("depth", C.c_uint8 * NPART), ("part_size", C.c_int8 * NPART), ("pred_mode", C.c_int8 * NPART),
+                ("tr_idx", C.c_uint8 * NPART), ("tskip", (C.c_uint8 * NPART) * 3), ("cbf", (C.c_uint8 * NPART) * 3),
+                ("intra_dir", (C.c_uint8 * NPART) * 2),
+                ("skip", C.c_uint8 * NPART), ("merge_flag", C.c_uint8 * NPART), ("merge_idx", C.c_uint8 * NPART),
+                ("inter_dir", C.c_uint8 * NPART), ("mvp_idx", C.c_int8 * NPART), ("ref_idx", C.c_int8 * NPART),
+                ("mv", (C.c_int16 * 2) * NPART), ("mvd", (C.c_int16 * 2) * NPART),
+                ("coef", (C.c_int32 * 4096) * 3)]
+
+
+class Yuv(C.Structure):
+    _fields_ = [("y", C.c_uint8 * 4096), ("u", C.c_uint8 * 1024), ("v", C.c_uint8 * 1024)]
+
+
+SIZE_2Nx2N, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN = 0, 1, 2, 3
+CI_CURR_BEST, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT = range(6)
+EV_INTRA_BEGIN, EV_INTRA_END, EV_INTER_BEGIN, EV_INTER_END, EV_MERGE_BEGIN, EV_MERGE_END = range(6)
+TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)
 
 
 def load():
@@ -56,6 +88,16 @@ def load():
     lib.hmo_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.hmo_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.hmo_decision_switch.argtypes = [C.c_void_p] * 5
+    lib.hmo_set_trace.argtypes = [C.c_void_p, TRACE_FN, C.c_void_p]
+    lib.hmo_test_cu.restype = C.POINTER(CU)
+    lib.hmo_test_cu.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hmo_test_reco.restype = C.POINTER(Yuv)
+    lib.hmo_test_reco.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hmo_test_slot.restype = C.POINTER(Cabac)
+    lib.hmo_test_slot.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.hmo_test_cur_ctu.argtypes = [C.c_void_p]
+    lib.hmo_test_last_luma_dist.argtypes = [C.c_void_p]
+    lib.hmo_test_last_luma_dist.restype = C.c_uint32
     return lib
 
 
@@ -94,9 +136,34 @@ class Encoder:
             out[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
         return out
 
-    def cabac(self):
+    def cabac(self, full=False):
+        """context states of [0][CI_CURR_BEST] after the last CTU: the 160 an I slice uses (all NCTX with full=True) + Q15 counter"""
         c = self.lib.hmo_get_cabac(self.h).contents
+        a = np.ctypeslib.as_array(c.ctx).copy()
+        return (a if full else a[:160]), int(c.frac)
+
+    # -- test hooks (hmo_int.h: trace)
+    def set_trace(self, fn):
+        """fn(event, depth, arg) around every CU candidate (EV_* above)"""
+        self._trace = TRACE_FN(lambda user, ev, d, a: fn(ev, d, a))
+        self.lib.hmo_set_trace(self.h, self._trace, None)
+
+    def test_cu(self, depth, best=False):
+        return self.lib.hmo_test_cu(self.h, depth, int(best)).contents
+
+    def test_reco(self, depth, best=False):
+        return self.lib.hmo_test_reco(self.h, depth, int(best)).contents
+
+    def test_slot(self, depth, ci):
+        c = self.lib.hmo_test_slot(self.h, depth, ci).contents
         return np.ctypeslib.as_array(c.ctx).copy(), int(c.frac)
+
+    def cur_ctu(self):
+        return self.lib.hmo_test_cur_ctu(self.h)
+
+    def last_luma_dist(self):
+        """luma distortion of the last intra candidate (what estIntraPredLumaQT left in the CU before chroma)"""
+        return self.lib.hmo_test_last_luma_dist(self.h)
 
     def set_decision(self, state, obf=None, sw_skip=(0, 0, 0, 0), sw_term=(0, 0, 0, 0), depth_exception=0):
         """Fork state of the frame + Naive decision switches per depth + the frame's OBF map (int16 [h/4, w/4])."""

@@ -75,6 +75,9 @@ static void cu_init(HmoCU *cu, int depth, int x, int y, int zidx)
   for (int c = 0; c < 3; c++) { memset(cu->tskip[c], 0, (size_t)n); memset(cu->cbf[c], 0, (size_t)n); }
   memset(cu->intra_dir[0], HMO_DC, (size_t)n);
   memset(cu->intra_dir[1], 0, (size_t)n);
+  memset(cu->skip, 0, (size_t)n); memset(cu->merge_flag, 0, (size_t)n); memset(cu->merge_idx, 0, (size_t)n); memset(cu->inter_dir, 0, (size_t)n);
+  memset(cu->mvp_idx, -1, (size_t)n); memset(cu->ref_idx, -1, (size_t)n);           /* clearMvField: NOT_VALID */
+  memset(cu->mv, 0, sizeof(cu->mv[0]) * (size_t)n); memset(cu->mvd, 0, sizeof(cu->mvd[0]) * (size_t)n);
   int s = HMO_CTU >> depth;
   memset(cu->coef[0], 0, sizeof(int32_t) * (size_t)(s * s));
   memset(cu->coef[1], 0, sizeof(int32_t) * (size_t)(s * s / 4));
@@ -92,6 +95,10 @@ static void cu_copy_part_from(HmoCU *dst, const HmoCU *src, int partUnitIdx)
   for (int c = 0; c < 3; c++) { memcpy(dst->tskip[c] + off, src->tskip[c], (size_t)n); memcpy(dst->cbf[c] + off, src->cbf[c], (size_t)n); }
   memcpy(dst->intra_dir[0] + off, src->intra_dir[0], (size_t)n);
   memcpy(dst->intra_dir[1] + off, src->intra_dir[1], (size_t)n);
+  memcpy(dst->skip + off, src->skip, (size_t)n); memcpy(dst->merge_flag + off, src->merge_flag, (size_t)n);
+  memcpy(dst->merge_idx + off, src->merge_idx, (size_t)n); memcpy(dst->inter_dir + off, src->inter_dir, (size_t)n);
+  memcpy(dst->mvp_idx + off, src->mvp_idx, (size_t)n); memcpy(dst->ref_idx + off, src->ref_idx, (size_t)n);
+  memcpy(dst->mv + off, src->mv, sizeof(src->mv[0]) * (size_t)n); memcpy(dst->mvd + off, src->mvd, sizeof(src->mvd[0]) * (size_t)n);
   memcpy(dst->coef[0] + off * 16, src->coef[0], sizeof(int32_t) * (size_t)(n * 16));
   memcpy(dst->coef[1] + off * 4, src->coef[1], sizeof(int32_t) * (size_t)(n * 4));
   memcpy(dst->coef[2] + off * 4, src->coef[2], sizeof(int32_t) * (size_t)(n * 4));
@@ -104,7 +111,10 @@ static void cu_copy_to_pic(HmoEnc *e, const HmoCU *cu)
   p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins;
   memcpy(p->depth + off, cu->depth, (size_t)n);
   memset(p->width + off, s, (size_t)n); memset(p->height + off, s, (size_t)n);
-  memset(p->skip + off, 0, (size_t)n);
+  memcpy(p->skip + off, cu->skip, (size_t)n);
+  memcpy(p->merge_flag + off, cu->merge_flag, (size_t)n); memcpy(p->merge_idx + off, cu->merge_idx, (size_t)n);
+  memcpy(p->inter_dir + off, cu->inter_dir, (size_t)n); memcpy(p->mvp_idx + off, cu->mvp_idx, (size_t)n); memcpy(p->ref_idx + off, cu->ref_idx, (size_t)n);
+  memcpy(p->mv + off, cu->mv, sizeof(cu->mv[0]) * (size_t)n); memcpy(p->mvd + off, cu->mvd, sizeof(cu->mvd[0]) * (size_t)n);
   memcpy(p->part_size + off, cu->part_size, (size_t)n);
   memcpy(p->pred_mode + off, cu->pred_mode, (size_t)n);
   memset(p->qp + off, e->p.qp, (size_t)n);
@@ -740,7 +750,9 @@ static int check_rd_cost_intra(HmoEnc *e, int d, int partSize)
   const int n = cu->nparts, s = cu_size(cu);
   memset(cu->part_size, partSize, (size_t)n);
   memset(cu->pred_mode, HMO_MODE_INTRA, (size_t)n);
+  if (e->trace) e->trace(e->trace_user, HMO_EV_INTRA_BEGIN, d, partSize);
   est_intra_pred_luma_qt(e, cu);
+  e->last_luma_dist = cu->dist;
   for (int y = 0; y < s; y++) memcpy(e->rec[0] + (cu->y + y) * e->stride[0] + cu->x, e->reco_temp[d]->y + y * 64, (size_t)s);
   est_intra_pred_chroma_qt(e, cu);
   hmo_reset_bits(e);
@@ -749,6 +761,7 @@ static int check_rd_cost_intra(HmoEnc *e, int d, int partSize)
   cu->bits = hmo_bits(e);
   cu->bins = e->goon_bins;
   cu->cost = calc_rd_cost(e, cu->bits, cu->dist);
+  if (e->trace) e->trace(e->trace_user, HMO_EV_INTRA_END, d, partSize);
   return check_best_mode(e, d);
 }
 
@@ -977,6 +990,13 @@ void hmo_decision_switch(const double *ver24, const double *th_skip, const doubl
   }
 }
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
+/* test hooks (see hmo_int.h: trace) */
+void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
+const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }
+const HmoYuv *hmo_test_reco(const HmoEnc *e, int d, int best) { return best ? e->reco_best[d] : e->reco_temp[d]; }
+const HmoCabac *hmo_test_slot(const HmoEnc *e, int d, int ci) { return d < 0 ? &e->goon : &e->slot[d][ci]; }
+int hmo_test_cur_ctu(const HmoEnc *e) { return e->cur_ctu; }
+uint32_t hmo_test_last_luma_dist(const HmoEnc *e) { return e->last_luma_dist; }
 const HmoCabac *hmo_get_cabac(const HmoEnc *e) { return &e->slot[0][CI_CURR_BEST]; }
 uint32_t hmo_ctu_replay_bits(const HmoEnc *e, int a) { return e->replay_bits[a]; }
 
@@ -989,6 +1009,7 @@ static void pic_ctu_init(const HmoEnc *e, HmoCtu *c)
   memset(c->width, HMO_CTU, HMO_NPART); memset(c->height, HMO_CTU, HMO_NPART);
   memset(c->qp, e->p.qp, HMO_NPART);
   memset(c->intra_dir[0], HMO_DC, HMO_NPART);
+  memset(c->mvp_idx, -1, HMO_NPART); memset(c->ref_idx, -1, HMO_NPART);
   c->total_cost = HMO_MAX_DOUBLE;
 }
 
@@ -999,7 +1020,7 @@ void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
   const int sliceStart = (ctuRsAddr / sliceLen) * sliceLen;
   int sliceEnd = sliceStart + sliceLen; if (sliceEnd > e->n_ctu) sliceEnd = e->n_ctu;
   e->cur_ctu = ctuRsAddr; e->slice_start = sliceStart;
-  if (ctuRsAddr == sliceStart) hmo_cabac_init(&e->slot[0][CI_CURR_BEST], e->p.qp);     /* resetEntropy */
+  if (ctuRsAddr == sliceStart) hmo_cabac_init_st(&e->slot[0][CI_CURR_BEST], e->p.qp, e->p.slice_type);     /* resetEntropy */
   pic_ctu_init(e, &e->pic[ctuRsAddr]);
   e->goon = e->slot[0][CI_CURR_BEST];
   e->goon_bins = 0;

@@ -42,6 +42,8 @@
 #include "TLibEncoder/TEncSbac.h"
 #include "TLibEncoder/TEncEntropy.h"
 #include "TLibEncoder/TEncBinCoderCABACCounter.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibEncoder/TEncSearch.h"
 #undef private
 #undef protected
 #include <math.h>
@@ -324,6 +326,148 @@ void ref_code_coeff(int ctu, int zidx, int depth, int nsplit, const int *path, i
   for (int i = 0; i < w * h; i++) q[i] = coef[i];
   g_sbac->codeCoeffNxN(*tu, q, c);
   free_tu(tc);
+}
+
+
+/* ==== the reference's PU / TU search loops (TEncSearch.cpp, compiled in place; build_ref.sh) ================================
+ * ref_search_setup builds what TEncTop::create / init build around a TEncSearch (TEncTop.cpp:94-231): the RD coder slots
+ * [depth][CI_*] on bit counters, the go-on coder, a TEncCfg carrying the search switches, and the per-depth CU / sample
+ * buffers of TEncCu::create (TEncCu.cpp:163-198).  The calls below are the calls TEncCu makes (cited per function); no
+ * search algorithm is restated here. */
+static TEncCfg *g_cfg = 0; static TEncSearch *g_search = 0;
+static TEncSbac ***g_rdSbac = 0; static TEncBinCABACCounter ***g_rdBin = 0;
+static TEncSbac *g_goOn = 0; static TEncBinCABACCounter *g_goOnBin = 0; static TComBitCounter *g_goOnBits = 0;
+static TComDataCU *g_tmpCU[4], *g_bestCU[4];
+static TComYuv *g_yOrg[4], *g_yPred[4], *g_yResi[4], *g_yResiBest[4], *g_yReco[4];
+
+int ref_search_setup(int searchRange, int fastSearch, int fastEnc, int hadME, int tsFast)
+{
+  if (!g_pic) return -1;
+  g_cfg = new TEncCfg();
+  g_cfg->m_chromaFormatIDC = CHROMA_420; g_cfg->m_uiQuadtreeTULog2MaxSize = 5; g_cfg->m_uiQuadtreeTULog2MinSize = 2;
+  g_cfg->m_iFastSearch = fastSearch; g_cfg->m_iSearchRange = searchRange; g_cfg->m_bipredSearchRange = 4;
+  g_cfg->m_bUseHADME = hadME != 0; g_cfg->m_bUseFastEnc = fastEnc != 0; g_cfg->m_useRDOQ = true; g_cfg->m_useRDOQTS = true;
+  g_cfg->m_rdPenalty = 0; g_cfg->m_reconBasedCrossCPredictionEstimate = false; g_cfg->m_useTransformSkipFast = tsFast != 0;
+  g_cfg->m_maxNumMergeCand = 5; g_cfg->m_costMode = COST_STANDARD_LOSSY;
+  g_rdSbac = new TEncSbac **[g_uiMaxCUDepth + 1]; g_rdBin = new TEncBinCABACCounter **[g_uiMaxCUDepth + 1];
+  for (UInt d = 0; d < g_uiMaxCUDepth + 1; d++) {
+    g_rdSbac[d] = new TEncSbac *[CI_NUM]; g_rdBin[d] = new TEncBinCABACCounter *[CI_NUM];
+    for (Int ci = 0; ci < CI_NUM; ci++) { g_rdSbac[d][ci] = new TEncSbac; g_rdBin[d][ci] = new TEncBinCABACCounter; g_rdSbac[d][ci]->init(g_rdBin[d][ci]); }
+  }
+  g_goOn = new TEncSbac; g_goOnBin = new TEncBinCABACCounter; g_goOn->init(g_goOnBin); g_goOnBits = new TComBitCounter;
+  g_search = new TEncSearch();
+  g_search->init(g_cfg, g_trq, searchRange, 4, fastSearch, g_ent, g_rd, g_rdSbac, g_goOn);
+  for (int d = 0; d < 4; d++) {
+    const UInt np = 1 << ((4 - d) << 1), w = 64 >> d;
+    g_tmpCU[d] = new TComDataCU; g_tmpCU[d]->create(CHROMA_420, np, w, w, false, 4);
+    g_bestCU[d] = new TComDataCU; g_bestCU[d]->create(CHROMA_420, np, w, w, false, 4);
+    TComYuv **all[5] = { g_yOrg, g_yPred, g_yResi, g_yResiBest, g_yReco };
+    for (int k = 0; k < 5; k++) { all[k][d] = new TComYuv; all[k][d]->create(w, w, CHROMA_420); }
+  }
+  return 0;
+}
+void ref_set_org(int comp, const unsigned char *plane)
+{
+  TComPicYuv *r = g_pic->getPicYuvOrg(); const ComponentID c = ComponentID(comp);
+  Pel *p = r->getAddr(c); const int s = r->getStride(c), w = r->getWidth(c), h = r->getHeight(c);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) p[y * s + x] = plane[y * w + x];
+}
+/* context states in HM's own order (m_contextModels) + the Q15 counter of one RD slot, or of the go-on coder (depth < 0) */
+static TEncSbac *coder_of(int depth, int ci) { return depth < 0 ? g_goOn : g_rdSbac[depth][ci]; }
+void ref_coder_set(int depth, int ci, const unsigned char *states, unsigned long long frac)
+{
+  TEncSbac *c = coder_of(depth, ci);
+  for (int i = 0; i < c->m_numContextModels; i++) c->m_contextModels[i].m_ucState = states[i];
+  ((TEncBinCABACCounter *)c->m_pcBinIf)->m_fracBits = frac;
+}
+unsigned long long ref_coder_get(int depth, int ci, unsigned char *states)
+{
+  TEncSbac *c = coder_of(depth, ci);
+  for (int i = 0; i < c->m_numContextModels; i++) states[i] = c->m_contextModels[i].m_ucState;
+  return ((TEncBinCABACCounter *)c->m_pcBinIf)->m_fracBits;
+}
+/* the temp CU of depth d positioned at (ctu, zidx): initCtu / initSubCU chain as xCompressCU descends (TEncCu.cpp:332,1337) */
+static TComDataCU *position_cu(int ctu, int zidx, int depth)
+{
+  g_tmpCU[0]->initCtu(g_pic, ctu);
+  for (int d = 1; d <= depth; d++) g_tmpCU[d]->initSubCU(g_tmpCU[d - 1], (zidx >> (2 * (4 - d))) & 3, d, g_qp);
+  if (depth == 0) g_tmpCU[0]->initEstData(0, g_qp, false);
+  return g_tmpCU[depth];
+}
+/* point the entropy front end at the go-on coder writing into a bit counter, as TEncSlice::compressSlice does before
+ * compressCtu (TEncSlice.cpp:1414-1420) */
+static void entropy_to_goon(void)
+{
+  g_ent->setEntropyCoder(g_goOn, g_slice);
+  g_ent->setBitstream(g_goOnBits);
+  g_goOnBin->setBinCountingEnableFlag(true);
+}
+struct RefCuOut {                    /* what the caller reads back: the temp CU after the call */
+  unsigned dist, bits, bins, dist_luma; double cost;
+  unsigned char luma_dir[256], chroma_dir[256], tr_idx[256], cbf[3][256], tskip[3][256];
+  unsigned char skip[256], merge_flag[256], merge_idx[256], inter_dir[256], part_size[256], pred_mode[256]; signed char mvp_idx[256], ref_idx[256];
+  short mv[256][2], mvd[256][2];
+  int coef[3][4096]; unsigned char reco[3][4096]; unsigned char pred[3][4096];
+};
+static void read_cu(TComDataCU *cu, int depth, RefCuOut *o)
+{
+  const int np = 256 >> (2 * depth), s = 64 >> depth;
+  o->dist = cu->getTotalDistortion(); o->bits = cu->getTotalBits(); o->bins = cu->getTotalBins(); o->cost = cu->getTotalCost();
+  for (int i = 0; i < np; i++) {
+    o->luma_dir[i] = cu->getIntraDir(CHANNEL_TYPE_LUMA)[i]; o->chroma_dir[i] = cu->getIntraDir(CHANNEL_TYPE_CHROMA)[i];
+    o->tr_idx[i] = cu->getTransformIdx()[i];
+    for (int c = 0; c < 3; c++) { o->cbf[c][i] = cu->getCbf(ComponentID(c))[i]; o->tskip[c][i] = cu->getTransformSkip(ComponentID(c))[i]; }
+    o->skip[i] = cu->getSkipFlag()[i]; o->merge_flag[i] = cu->getMergeFlag()[i]; o->merge_idx[i] = cu->getMergeIndex()[i];
+    o->inter_dir[i] = cu->getInterDir()[i]; o->part_size[i] = (unsigned char)cu->getPartitionSize()[i]; o->pred_mode[i] = (unsigned char)cu->getPredictionMode()[i];
+    o->mvp_idx[i] = cu->getMVPIdx(REF_PIC_LIST_0)[i]; o->ref_idx[i] = cu->getCUMvField(REF_PIC_LIST_0)->getRefIdx(i);
+    const TComMv &m = cu->getCUMvField(REF_PIC_LIST_0)->getMv(i), &dm = cu->getCUMvField(REF_PIC_LIST_0)->getMvd(i);
+    o->mv[i][0] = m.getHor(); o->mv[i][1] = m.getVer(); o->mvd[i][0] = dm.getHor(); o->mvd[i][1] = dm.getVer();
+  }
+  for (int c = 0; c < 3; c++) {
+    const int n = c ? (s / 2) * (s / 2) : s * s, w = c ? s / 2 : s;
+    const TCoeff *q = cu->getCoeff(ComponentID(c));
+    for (int i = 0; i < n; i++) o->coef[c][i] = q[i];
+    const Pel *r = g_yReco[depth]->getAddr(ComponentID(c)); const int rs = g_yReco[depth]->getStride(ComponentID(c));
+    const Pel *pp = g_yPred[depth]->getAddr(ComponentID(c)); const int ps = g_yPred[depth]->getStride(ComponentID(c));
+    for (int y = 0; y < w; y++) for (int x = 0; x < w; x++) { o->reco[c][y * w + x] = (unsigned char)r[y * rs + x]; o->pred[c][y * w + x] = (unsigned char)pp[y * ps + x]; }
+  }
+}
+/* One intra CU candidate through the reference: the body of TEncCu::xCheckRDCostIntra (TEncCu.cpp:2064-2141) --
+ * estIntraPredLumaQT, luma reconstruction to the picture, estIntraPredChromaQT, the CU's syntax on the go-on coder,
+ * calcRdCost.  The caller has loaded the picture state the search reads: PicYuvOrg, PicYuvRec (ref_set_org / ref_set_rec),
+ * the CTUs' decided arrays (ref_set_ctu_field) and the coder slot [depth][CI_CURR_BEST] (ref_coder_set).
+ * `stage`: 1 = luma search only (BASELINE configs[1]), 2 = luma + chroma + CU bits. */
+int ref_intra_cu(int ctu, int zidx, int depth, int partSize, int stage, RefCuOut *out)
+{
+  TComDataCU *cu = position_cu(ctu, zidx, depth);
+  entropy_to_goon();
+  g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);                                     /* TEncSlice.cpp:1417 / TEncCu.cpp:1343-1347 */
+  g_yOrg[depth]->copyFromPicYuv(g_pic->getPicYuvOrg(), ctu, zidx);                  /* TEncCu.cpp:474 */
+  cu->setSkipFlagSubParts(false, 0, depth);
+  cu->setPartSizeSubParts(PartSize(partSize), 0, depth);
+  cu->setPredModeSubParts(MODE_INTRA, 0, depth);
+  cu->setChromaQpAdjSubParts(0, 0, depth);
+  static Pel resiLuma[NUMBER_OF_STORED_RESIDUAL_TYPES][MAX_CU_SIZE * MAX_CU_SIZE];
+  g_search->estIntraPredLumaQT(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], resiLuma);
+  out->dist_luma = cu->getTotalDistortion();
+  if (stage >= 2) {
+    g_yReco[depth]->copyToPicComponent(COMPONENT_Y, g_pic->getPicYuvRec(), ctu, zidx);
+    g_search->estIntraPredChromaQT(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], resiLuma);
+    g_ent->resetBits();
+    g_ent->encodeSkipFlag(cu, 0, true);
+    g_ent->encodePredMode(cu, 0, true);
+    g_ent->encodePartSize(cu, 0, depth, true);
+    g_ent->encodePredInfo(cu, 0);
+    g_ent->encodeIPCMInfo(cu, 0, true);
+    Bool dqp = false, cqa = false;
+    g_ent->encodeCoeff(cu, 0, depth, dqp, cqa);
+    g_goOn->store(g_rdSbac[depth][CI_TEMP_BEST]);
+    cu->getTotalBits() = g_ent->getNumberOfWrittenBits();
+    cu->getTotalBins() = g_goOnBin->getBinsCoded();
+    cu->getTotalCost() = g_rd->calcRdCost(cu->getTotalBits(), cu->getTotalDistortion());
+  }
+  read_cu(cu, depth, out);
+  return 0;
 }
 
 } /* extern "C" */

@@ -33,7 +33,7 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, int tools, c
 }
 void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); delete e; }
 void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, a); e->c.next_ctu = a + 1; }
-void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX); *frac = e->c.state.frac; }
+void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX_INTRA); *frac = e->c.state.frac; }
 void fcu_emu_set_decision(void *h, int state, const uint8_t *sw_skip, const uint8_t *sw_term, int depth_exception, const int16_t *obf)
 {
   Chain &c = ((EmuChain *)h)->c;

@@ -1,7 +1,9 @@
-"""Fork pre-pass (outlier-block-flag map, TEncSlice::getOutlierWithDCT): oracle self-consistency on CPU, the HIP
-kernels against the oracle on the GPU.  Parity of the threshold fit with the reference itself is UNPINNED (the
-pre-pass lives in TEncSlice.cpp, which cannot be built in the container); the 4x4 DCT underneath is the leaf-pinned one."""
+"""Fork pre-pass (outlier-block-flag map, TEncSlice::getOutlierWithDCT): the threshold fit against golden vectors from the
+REFERENCE'S OWN TCMprocessOneSequence (tests/golden/tcm.npz, oracle/ref/make_golden_tcm.py: TEncSlice.cpp:193-392 compiled
+in place), oracle self-consistency on CPU, the HIP kernels against the oracle on the GPU.  The 4x4 DCT underneath is the
+leaf-pinned one; the loop that feeds the fit (getOutlierWithDCT itself, a TEncSlice member) stays restated by reading."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -52,6 +54,30 @@ def test_threshold_of_a_laplacian_with_outliers():
     err = C.c_int(0)
     yc = hmo_py.load().hmo_tcm_threshold(C.c_void_p(hist.ctypes.data), int(amp.max()), int(amp.size), C.cast(C.byref(err), C.c_void_p))
     assert err.value == 0 and bulk.max() * 0.5 < yc < 150
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tcm.npz")
+
+
+def test_tcm_fit_matches_the_reference(built, pkg):
+    """Oracle restatement and the engine's host-side fit (libfcu.so, host arithmetic) == the reference's Yc on every case
+    where the reference's result is defined (peak >= 3, or all-zero input)."""
+    g = np.load(GOLD)
+    lo, le = hmo_py.load(), pkg.load_lib()
+    n_def = 0
+    for i in range(len(g["len"])):
+        if not g["defined"][i]:
+            continue                                            # FindStartPoint reads uninitialised buckets there (peak 1, 2)
+        n_def += 1
+        peak, n = int(g["peak"][i]), int(g["len"][i])
+        hist = np.ascontiguousarray(g["hist"][i][:max(peak, 0) + 1], np.int32)
+        err = C.c_int(0)
+        yo = lo.hmo_tcm_threshold(C.c_void_p(hist.ctypes.data), peak, n, C.cast(C.byref(err), C.c_void_p))
+        assert err.value == 0 and yo == g["yc"][i], (i, peak, n, yo, g["yc"][i])
+        hu = hist.astype(np.uint32)
+        ye = le.fcu_tcm_threshold(hu.ctypes.data, hu.size, n)
+        assert ye == g["yc"][i], (i, peak, n, ye, g["yc"][i])
+    assert n_def >= 20
 
 
 @pytest.mark.gpu
