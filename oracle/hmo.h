@@ -151,6 +151,8 @@ void    hmo_destroy(HmoEnc *e);
 /* planes: 8-bit 4:2:0.  rec planes are written (picture-sized, stride = plane width). */
 void    hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const uint8_t *orgV,
                        uint8_t *recY, uint8_t *recU, uint8_t *recV);
+/* P slice: the reference picture (list 0, index 0), i.e. the previous picture after the loop filters */
+void    hmo_set_ref_planes(HmoEnc *e, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV);
 /* compressCtu + encodeCtu replay for CTU ctuRsAddr (must be called in raster order). */
 void    hmo_compress_ctu(HmoEnc *e, int ctuRsAddr);
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int ctuRsAddr);

@@ -51,6 +51,7 @@ void hmo_enc_bin_trm(HmoEnc *e, int bin)
 int hmo_coef_scan_idx(const HmoCU *cu, int part, int log2, int comp)
 {
   int maxlog2 = comp ? 2 : 3;                    /* MDCS_MAXIMUM_WIDTH 8 >> chroma scale */
+  if (cu->pred_mode[part] != HMO_MODE_INTRA) return 0;   /* SCAN_DIAG for inter CUs (:3360) */
   if (log2 > maxlog2) return 0;
   int dir = cu->intra_dir[comp ? 1 : 0][part];
   if (dir == HMO_DM_CHROMA) dir = cu->intra_dir[0][part & ~3];

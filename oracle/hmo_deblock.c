@@ -1,7 +1,7 @@
 /*
  * hmo_deblock.c -- ORACLE (test infrastructure, never shipped / never on the product path).
  *
- * CPU restatement of HM's in-loop deblocking of an all-intra picture, TComLoopFilter::loopFilterPic
+ * CPU restatement of HM's in-loop deblocking of an intra or P picture, TComLoopFilter::loopFilterPic
  * (Lib/TLibCommon/TComLoopFilter.cpp:130-155) with xDeblockCU (:170-236), the edge flags of xSetEdgefilterTU /
  * xSetEdgefilterPU / xSetLoopfilterParam (:270-405), the intra branch of xGetBoundaryStrengthSingle (:436-440),
  * xEdgeFilterLuma (:557-667), xEdgeFilterChroma (:670-791) and the sample filters (:805-946), as configured by
@@ -9,7 +9,8 @@
  *
  * Restated per picture position instead of per CU: with 4-sample partitions (g_uiMaxCUWidth >> g_uiMaxCUDepth = 4)
  * an edge is filtered where it lies on the 8-sample grid (PartIdxIncr = 2, :207-213) and the partition on its Q side
- * starts a transform unit there (every CU / NxN-PU edge is also a TU edge); intra pictures have Bs = 2 everywhere.
+ * starts a transform unit or a prediction unit there; Bs = 2 next to an intra CU, else 1 across a transform edge with a
+ * coded luma block on either side or across different motion (one reference list: P slices), else 0 (:405-553).
  * All vertical edges of the picture are filtered before the first horizontal one (:133-154).
  *
  * Parity: PINNED -- tests/golden/deblock_*.npz hold the output of the reference's own TComLoopFilter (built in place
@@ -46,8 +47,23 @@ static int edge_flag(const Dbk *d, int dir, int x4, int y4)
   if (c->part_size[z] == HMO_SIZE_NONE) return 0;                     /* outside the picture, :172 */
   const int pos = (dir == 0 ? x4 : y4) * 4;
   if (pos == 0) return 0;
-  const int tu = (HMO_CTU >> c->depth[z]) >> c->tr_idx[z];
-  return (pos % tu) == 0;
+  const int cu = HMO_CTU >> c->depth[z], tu = cu >> c->tr_idx[z];
+  if ((pos % tu) == 0) return 1;                                      /* transform-unit (or CU) edge: m_aapucBS starts at 1 */
+  /* prediction-unit edge inside the CU (xSetEdgefilterPU, :322-356): not a transform edge, m_aapucBS starts at 0 */
+  if (c->part_size[z] == HMO_SIZE_2NxN && dir == 1 && (pos % cu) == cu / 2) return 2;
+  if (c->part_size[z] == HMO_SIZE_Nx2N && dir == 0 && (pos % cu) == cu / 2) return 2;
+  if (c->part_size[z] == HMO_SIZE_NxN && (pos % cu) == cu / 2) return 2;
+  return 0;
+}
+/* xGetBoundaryStrengthSingle, :405-553 (P slices with one reference picture list): P = left / above partition */
+static int boundary_strength(const Dbk *d, int flag, int x4, int y4, int px4, int py4)
+{
+  int zq, zp; const HmoCtu *q = part_at(d, x4, y4, &zq), *p = part_at(d, px4, py4, &zp);
+  if (p->pred_mode[zp] == HMO_MODE_INTRA || q->pred_mode[zq] == HMO_MODE_INTRA) return 2;
+  if (flag == 1 && ((((q->cbf[0][zq] >> q->tr_idx[zq]) & 1) != 0) || (((p->cbf[0][zp] >> p->tr_idx[zp]) & 1) != 0))) return 1;
+  const int rp = p->ref_idx[zp], rq = q->ref_idx[zq];
+  const int mpx = rp < 0 ? 0 : p->mv[zp][0], mpy = rp < 0 ? 0 : p->mv[zp][1], mqx = rq < 0 ? 0 : q->mv[zq][0], mqy = rq < 0 ? 0 : q->mv[zq][1];
+  return ((rp < 0) != (rq < 0) || (rp >= 0 && rp != rq) || iabs(mqx - mpx) >= 4 || iabs(mqy - mpy) >= 4) ? 1 : 0;
 }
 static int qp_at(const Dbk *d, int x4, int y4) { int z; const HmoCtu *c = part_at(d, x4, y4, &z); return c->qp[z]; }
 
@@ -85,9 +101,9 @@ static int calc_dq(const uint8_t *p, int o) { return iabs(p[0] - 2 * p[o] + p[2 
 
 /* one 4-sample segment of a luma edge, the loop body of xEdgeFilterLuma (:597-665).  p: first sample of the Q side on
  * the segment's first line, o: step across the edge, step: step along it */
-static void luma_segment(uint8_t *p, int o, int step, int qp, int betaOff, int tcOff)
+static void luma_segment(uint8_t *p, int o, int step, int qp, int betaOff, int tcOff, int bs)
 {
-  const int tc = k_tc[clip3(0, 53, qp + 2 * (2 - 1) + tcOff * 2)];       /* Bs = 2, DEFAULT_INTRA_TC_OFFSET = 2 */
+  const int tc = k_tc[clip3(0, 53, qp + 2 * (bs - 1) + tcOff * 2)];      /* DEFAULT_INTRA_TC_OFFSET = 2 */
   const int beta = k_beta[clip3(0, 51, qp + betaOff * 2)];
   const int side = (beta + (beta >> 1)) >> 3, thrCut = tc * 10;
   const int dp0 = calc_dp(p, o), dq0 = calc_dq(p, o), dp3 = calc_dp(p + 3 * step, o), dq3 = calc_dq(p + 3 * step, o);
@@ -120,13 +136,16 @@ void hmo_deblock_pic(const HmoCtu *pic, int width, int height, uint8_t *recY, ui
     for (int y4 = 0; y4 < h4; y4++)
       for (int x4 = 0; x4 < w4; x4++) {
         const int pos4 = dir == 0 ? x4 : y4;
-        if ((pos4 & 1) || !edge_flag(&d, dir, x4, y4)) continue;       /* 8-sample grid, :207-213 */
+        int flag;
+        if ((pos4 & 1) || !(flag = edge_flag(&d, dir, x4, y4))) continue;       /* 8-sample grid, :207-213 */
+        const int bs = boundary_strength(&d, flag, x4, y4, dir == 0 ? x4 - 1 : x4, dir == 0 ? y4 : y4 - 1);
+        if (bs == 0) continue;
         const int qpQ = qp_at(&d, x4, y4), qpP = dir == 0 ? qp_at(&d, x4 - 1, y4) : qp_at(&d, x4, y4 - 1);
         const int qp = (qpP + qpQ + 1) >> 1;
         uint8_t *p = recY + (y4 * 4) * width + x4 * 4;
-        if (dir == 0) luma_segment(p, 1, width, qp, betaOffsetDiv2, tcOffsetDiv2);
-        else luma_segment(p, width, 1, qp, betaOffsetDiv2, tcOffsetDiv2);
-        if ((pos4 & 3) == 0) {                                         /* chroma: 8-sample chroma grid, :216-221,700-707 */
+        if (dir == 0) luma_segment(p, 1, width, qp, betaOffsetDiv2, tcOffsetDiv2, bs);
+        else luma_segment(p, width, 1, qp, betaOffsetDiv2, tcOffsetDiv2, bs);
+        if ((pos4 & 3) == 0 && bs == 2) {                              /* chroma only across intra edges (:723) */                                         /* chroma: 8-sample chroma grid, :216-221,700-707 */
           int qc = qp;                                                 /* cb / cr QP offsets 0 */
           if (qc >= 58) qc -= 6; else if (qc >= 0) qc = k_chroma_scale[qc];       /* :747-761 */
           const int tc = k_tc[clip3(0, 53, qc + 2 * (2 - 1) + tcOffsetDiv2 * 2)];

@@ -66,6 +66,7 @@ struct HmoEnc {
   int w_ctu, h_ctu, n_ctu;
   const uint8_t *org[3];
   uint8_t *rec[3];
+  const uint8_t *ref[3];             /* P slice: reference picture (list 0, index 0) = previous picture after the loop filters */
   int stride[3];
   HmoCtu *pic;                       /* per-CTU committed decisions (TComPic CTU objects) */
   uint32_t *replay_bits;
@@ -84,6 +85,10 @@ struct HmoEnc {
   HmoYuv  ts_rec;                    /* m_pcQTTempTransformSkipTComYuv */
   uint8_t shared_pred[3][32 * 32];   /* m_pSharedPredTransformSkip */
   uint8_t tmp_tr_idx[HMO_NPART], tmp_cbf[3][HMO_NPART], tmp_tskip[3][HMO_NPART];
+  /* inter: residual of the CU, best residual, residual per RQT layer (m_pcQTTempTComYuv holds residuals on this path), m_tmpYuvPred */
+  HmoYuv16 resi_cu, resi_best, qt_resi[4];
+  HmoYuv  tmp_pred;
+  uint64_t n_sad;                    /* integer-search positions evaluated */
   /* current slice */
   int slice_start;                   /* first CTU (raster) of the slice containing the current CTU */
   int cur_ctu;

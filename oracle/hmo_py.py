@@ -33,6 +33,7 @@ class Ctu(C.Structure):
                 ("total_bins", C.c_uint32)]
 
 
+SLICE_I, SLICE_P = 0, 1
 NCTX = 176                                   # HMO_NCTX: 160 intra contexts + the inter syntax (hmo.h)
 
 
@@ -71,6 +72,9 @@ def load():
     lib.hmo_params_default.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
     lib.hmo_params_finish.argtypes = [C.POINTER(Params)]
     lib.hmo_set_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.hmo_set_ref_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+    lib.hmo_test_n_sad.restype = C.c_uint64
+    lib.hmo_test_n_sad.argtypes = [C.c_void_p]
     lib.hmo_compress_ctu.argtypes = [C.c_void_p, C.c_int]
     lib.hmo_compress_frame.argtypes = [C.c_void_p]
     lib.hmo_get_ctu.restype = C.POINTER(Ctu)
@@ -104,13 +108,20 @@ def load():
 class Encoder:
     """One chain: a frame (or its slices) decided CTU by CTU in raster order."""
 
-    def __init__(self, Y, U, V, qp, slice_ctus=0, **flags):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, ref=None, **flags):
+        """ref = (Y, U, V) planes of the reference picture makes this a P picture (slice_type P, list 0, index 0);
+        flags: any Params field (search_range, fast_enc, lambda_override, ...)."""
         self.lib = load()
         h, w = Y.shape
         self.p = Params()
         self.lib.hmo_params_default(C.byref(self.p), w, h, qp)
         self.p.slice_ctus = slice_ctus
+        if ref is not None:
+            self.p.slice_type = SLICE_P
+        known = {n for n, _ in Params._fields_}
         for k, v in flags.items():
+            if k not in known:
+                raise TypeError(f"unknown oracle parameter {k!r}")
             setattr(self.p, k, v)
         self.lib.hmo_params_finish(C.byref(self.p))
         self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
@@ -118,6 +129,10 @@ class Encoder:
         self.h = self.lib.hmo_create(C.byref(self.p))
         self.lib.hmo_set_planes(self.h, *[a.ctypes.data for a in self.org], *[a.ctypes.data for a in self.rec])
         self.n_ctu = self.lib.hmo_num_ctus(self.h)
+        self.ref = None
+        if ref is not None:
+            self.ref = [np.ascontiguousarray(a, dtype=np.uint8) for a in ref]
+            self.lib.hmo_set_ref_planes(self.h, *[a.ctypes.data for a in self.ref])
 
     def compress_ctu(self, a):
         self.lib.hmo_compress_ctu(self.h, a)
@@ -196,6 +211,39 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+
+def ldp_slice(poc, base_qp, gop=((3, 0.4624), (2, 0.4624), (3, 0.4624), (1, 0.578)), had_me=True):
+    """Slice QP and lambda of picture `poc` under HM's encoder_lowdelay_P_main GOP table (QP offset, QP factor of Frame1..4)
+    as TEncSlice::initEncSlice derives them (TEncSlice.cpp:560-740): returns (slice_type, qp, lambda)."""
+    n = len(gop)
+    if poc == 0:
+        scale = 1.0 - min(0.5, max(0.0, 0.05 * (n - 1)))
+        return SLICE_I, base_qp, 0.57 * scale * 2.0 ** ((base_qp - 12) / 3.0)
+    off, factor = gop[(poc - 1) % n]
+    qp = base_qp + off
+    r = poc % n
+    depth = 0
+    if r:
+        step, i = n, n >> 1
+        while i >= 1:
+            j, hit = i, False
+            while j < n:
+                if j == r:
+                    hit = True
+                    break
+                j += step
+            step >>= 1
+            depth += 1
+            if hit:
+                break
+            i >>= 1
+    lam = factor * 2.0 ** ((qp - 12) / 3.0)
+    if depth > 0:
+        lam *= min(4.0, max(2.0, (qp - 12) / 6.0))
+    if not had_me:
+        lam *= 0.95
+    return SLICE_P, qp, lam
 
 
 def obf_prepass(Y):

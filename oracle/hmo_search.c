@@ -163,6 +163,9 @@ static int intra_dir_predictor(const HmoEnc *e, const HmoCU *cu, int part, int p
 /* ------------------------------------------------------------------------------------
  * syntax elements (TEncSbac.cpp)
  * ---------------------------------------------------------------------------------- */
+static void code_skip_flag(HmoEnc *e, const HmoCU *cu, int part);      /* hmo_inter.h */
+static void code_pred_mode(HmoEnc *e, const HmoCU *cu, int part);
+static void encode_cu_syntax_inter(HmoEnc *e, const HmoCU *cu, int cuPart, int depth);
 /* codeSplitFlag, TEncSbac.cpp:613-628 + getCtxSplitFlag, TComDataCU.cpp:1626-1640 */
 static void code_split_flag(HmoEnc *e, const HmoCU *cu, int part, int depth)
 {
@@ -269,6 +272,7 @@ static void enc_coeff_qt(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp, 
 static void enc_intra_header(HmoEnc *e, const HmoCU *cu, int trDepth, int part, int bLuma, int bChroma)
 {
   if (bLuma) {
+    if (part == 0 && e->p.slice_type != HMO_SLICE_I) { code_skip_flag(e, cu, 0); code_pred_mode(e, cu, 0); }   /* TEncSearch.cpp:990-1000 */
     if (part == 0) code_part_size(e, cu, 0, cu->depth[0]);
     if (cu->part_size[0] == HMO_SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(e, cu, 0, 0); }
     else { int q = cu->nparts >> 2; if (trDepth > 0 && (part % q) == 0) code_intra_dir_luma(e, cu, part, 0); }
@@ -721,6 +725,10 @@ static void encode_transform(HmoEnc *e, const HmoCU *cu, int cuPart, const HmoTU
 /* CU syntax as coded by xCheckRDCostIntra (TEncCu.cpp:2117-2141) and xEncodeCU (:1753-1778) */
 static void encode_cu_syntax(HmoEnc *e, const HmoCU *cu, int cuPart, int depth)
 {
+  if (e->p.slice_type != HMO_SLICE_I) {                        /* encodeSkipFlag / encodePredMode are no-ops in I slices */
+    if (cu->pred_mode[cuPart] == HMO_MODE_INTER) { encode_cu_syntax_inter(e, cu, cuPart, depth); return; }
+    code_skip_flag(e, cu, cuPart); code_pred_mode(e, cu, cuPart);
+  }
   code_part_size(e, cu, cuPart, depth);
   code_intra_dir_luma(e, cu, cuPart, 1);                       /* encodePredInfo */
   code_intra_dir_chroma(e, cu, cuPart);
@@ -730,6 +738,8 @@ static void encode_cu_syntax(HmoEnc *e, const HmoCU *cu, int cuPart, int depth)
   root.cw = root.cwo = (HMO_CTU >> depth) >> 1; root.c_code_all = 1;
   encode_transform(e, cu, cuPart, &root);
 }
+
+#include "hmo_inter.h"
 
 /* ------------------------------------------------------------------------------------
  * xCheckRDCostIntra, TEncCu.cpp:2064-2157 ; xCheckBestMode :2213-2255
@@ -827,10 +837,20 @@ static void compress_cu(HmoEnc *e, int d)
       memcpy(e->org_yuv[d]->v + yy * 32, e->org[2] + (y / 2 + yy) * e->stride[2] + x / 2, (size_t)(s / 2));
     }
     cu_init(e->temp[d], d, x, y, zidx);
-    if (!skip2Nx2N) check_rd_cost_intra(e, d, HMO_SIZE_2Nx2N);  /* :1040; skipped => best cost stays MAX_DOUBLE (:1077) */
+    int tryIntra = 1;
+    if (e->p.slice_type == HMO_SLICE_P) {                       /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
+      check_rd_cost_merge_2nx2n(e, d);                          /* :774 */
+      cu_init(e->temp[d], d, x, y, zidx);
+      check_rd_cost_inter(e, d, HMO_SIZE_2Nx2N); cu_init(e->temp[d], d, x, y, zidx);      /* :780 */
+      check_rd_cost_inter(e, d, HMO_SIZE_Nx2N); cu_init(e->temp[d], d, x, y, zidx);       /* :826 (inter NxN never: 8x8 CUs are excluded, :816) */
+      check_rd_cost_inter(e, d, HMO_SIZE_2NxN); cu_init(e->temp[d], d, x, y, zidx);       /* :835 */
+      const HmoCU *b = e->best[d];                              /* intra only when the best inter candidate has a residual (:1033-1036) */
+      tryIntra = b->cbf[0][0] != 0 || b->cbf[1][0] != 0 || b->cbf[2][0] != 0;
+    }
+    if (!skip2Nx2N && tryIntra) check_rd_cost_intra(e, d, HMO_SIZE_2Nx2N);  /* :1040; skipped => best cost stays MAX_DOUBLE (:1077) */
     j0 = e->best[d]->cost;                                      /* :1072,1078 */
     cu_init(e->temp[d], d, x, y, zidx);
-    if (d == HMO_MAXDEPTH && !earlyTerminate) {                 /* :1141-1143 */
+    if (d == HMO_MAXDEPTH && !earlyTerminate && tryIntra) {     /* :1141-1143 */
       partitionTrue = check_rd_cost_intra(e, d, HMO_SIZE_NxN);
       j1 = partitionTrue ? e->best[d]->cost : e->temp[d]->cost; /* :1175-1183 */
       cu_init(e->temp[d], d, x, y, zidx);
@@ -922,6 +942,7 @@ void hmo_params_default(HmoParams *p, int width, int height, int qp)
   memset(p, 0, sizeof(*p));
   p->width = width; p->height = height; p->qp = qp; p->slice_ctus = 0;
   p->transform_skip = 1; p->transform_skip_fast = 1; p->sign_hiding = 1; p->strong_smoothing = 1;
+  p->slice_type = HMO_SLICE_I; p->search_range = 64; p->fast_search = 0; p->fast_enc = 1; p->had_me = 1; p->fdm = 1; p->max_merge_cand = 5;
   hmo_params_finish(p);
 }
 /* TEncSlice::initEncSlice lambda (TEncSlice.cpp:686-706) + setUpLambda (:496-524) + TComRdCost::setLambda */
@@ -929,7 +950,10 @@ void hmo_params_finish(HmoParams *p)
 {
   double qp_temp = (double)p->qp - 12;
   double lambda = 0.57 * pow(2.0, qp_temp / 3.0);
+  if (p->lambda_override > 0.0) lambda = p->lambda_override;   /* non-I slices: QP factor of the GOP entry etc., computed by the caller */
   p->lambda = lambda;
+  p->lambda_motion_sad = (unsigned)floor(65536.0 * sqrt(lambda));   /* TComRdCost::setLambda, TComRdCost.cpp:194-219 */
+  p->lambda_motion_sse = (unsigned)floor(65536.0 * lambda);
   p->sqrt_lambda = sqrt(lambda);
   int qpc = p->qp < 0 ? p->qp : hmo_chroma_scale[p->qp > 57 ? 57 : p->qp];
   p->qp_c = qpc;
@@ -965,6 +989,9 @@ void hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const u
   e->rec[0] = recY; e->rec[1] = recU; e->rec[2] = recV;
   e->stride[0] = e->p.width; e->stride[1] = e->stride[2] = e->p.width / 2;
 }
+/* reference picture of a P slice (list 0, index 0): planes of the picture size, same strides as the reconstruction */
+void hmo_set_ref_planes(HmoEnc *e, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV) { e->ref[0] = refY; e->ref[1] = refU; e->ref[2] = refV; }
+uint64_t hmo_test_n_sad(const HmoEnc *e) { return e->n_sad; }
 int hmo_num_ctus(const HmoEnc *e) { return e->n_ctu; }
 /* fork state of the frame (getCurrentState, tools_YS.cpp:1237-1242), the per-depth decision switches of the Naive model
  * (g_bDecisionSwitch[depth][Naive][Skip2Nx2N / TerminateCU]) and the frame's OBF count map ((height/4) x (width/4));
@@ -1038,6 +1065,9 @@ void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
     memcpy(view->pred_mode, p->pred_mode, HMO_NPART); memcpy(view->tr_idx, p->tr_idx, HMO_NPART);
     for (int c = 0; c < 3; c++) { memcpy(view->tskip[c], p->tskip[c], HMO_NPART); memcpy(view->cbf[c], p->cbf[c], HMO_NPART); }
     memcpy(view->intra_dir[0], p->intra_dir[0], HMO_NPART); memcpy(view->intra_dir[1], p->intra_dir[1], HMO_NPART);
+    memcpy(view->skip, p->skip, HMO_NPART); memcpy(view->merge_flag, p->merge_flag, HMO_NPART); memcpy(view->merge_idx, p->merge_idx, HMO_NPART);
+    memcpy(view->inter_dir, p->inter_dir, HMO_NPART); memcpy(view->mvp_idx, p->mvp_idx, HMO_NPART); memcpy(view->ref_idx, p->ref_idx, HMO_NPART);
+    memcpy(view->mv, p->mv, sizeof(p->mv)); memcpy(view->mvd, p->mvd, sizeof(p->mvd));
     memcpy(view->coef[0], p->coeff_y, sizeof(p->coeff_y)); memcpy(view->coef[1], p->coeff_cb, sizeof(p->coeff_cb)); memcpy(view->coef[2], p->coeff_cr, sizeof(p->coeff_cr));
     e->goon = e->slot[0][CI_CURR_BEST];
     hmo_reset_bits(e);

@@ -281,6 +281,7 @@ int hmo_rdoq(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp, const int32_
   int bestLastIdxP1 = 0;
   {
     int ctxCbf = ch ? (HMO_CTX_CBF_CHROMA + tu->tr_depth) : (HMO_CTX_CBF_LUMA + (tu->tr_depth == 0 ? 1 : 0));
+    if (cu->pred_mode[part] != HMO_MODE_INTRA && !ch && cu->tr_idx[part] == 0) ctxCbf = HMO_CTX_ROOT_CBF;   /* blockRootCbpBits[0], TComTrQuant.cpp:2358-2363 */
     bestCost = blockUncodedCost + lambda * (double)hmo_ctx_bits(c, ctxCbf, 0);
     baseCost += lambda * (double)hmo_ctx_bits(c, ctxCbf, 1);
   }

@@ -76,7 +76,7 @@ int ref_setup(int width, int height, int qp)
   g_sps.setLog2MinCodingBlockSize(3); g_sps.setLog2DiffMaxMinCodingBlockSize(3);
   g_sps.setQuadtreeTULog2MaxSize(5); g_sps.setQuadtreeTULog2MinSize(2);
   g_sps.setQuadtreeTUMaxDepthInter(3); g_sps.setQuadtreeTUMaxDepthIntra(3);
-  g_sps.setMaxTrSize(32); g_sps.setUsePCM(false); g_sps.setUseAMP(true);
+  g_sps.setMaxTrSize(32); g_sps.setUsePCM(false); g_sps.setUseAMP(false);   /* AMP 0: the inter configuration built; no effect on intra */
   g_sps.setBitDepth(CHANNEL_TYPE_LUMA, 8); g_sps.setBitDepth(CHANNEL_TYPE_CHROMA, 8);
   g_sps.setQpBDOffset(CHANNEL_TYPE_LUMA, 0); g_sps.setQpBDOffset(CHANNEL_TYPE_CHROMA, 0);
   g_sps.setUseStrongIntraSmoothing(true);
@@ -468,6 +468,95 @@ int ref_intra_cu(int ctu, int zidx, int depth, int partSize, int stage, RefCuOut
   }
   read_cu(cu, depth, out);
   return 0;
+}
+
+
+/* ==== P slices: one reference picture (list 0), TMVP off, MaxNumMergeCand 5 ================================================== */
+static TComPic *g_refpic = 0;
+/* slice type, reference picture planes and the slice lambda (TEncSlice::setUpLambda) */
+int ref_setup_p(const unsigned char *ry, const unsigned char *ru, const unsigned char *rv, double lambda)
+{
+  if (!g_pic) return -1;
+  if (!g_refpic) { g_refpic = new TComPic(); g_refpic->create(g_sps, g_pps, 64, 64, 4, false); }
+  const unsigned char *pl[3] = { ry, ru, rv };
+  for (int c = 0; c < 3; c++) {
+    TComPicYuv *r = g_refpic->getPicYuvRec(); const ComponentID id = ComponentID(c);
+    Pel *p = r->getAddr(id); const int s = r->getStride(id), w = r->getWidth(id), h = r->getHeight(id);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) p[y * s + x] = pl[c][y * w + x];
+  }
+  g_refpic->getPicYuvRec()->setBorderExtension(false);
+  g_refpic->getPicYuvRec()->extendPicBorder();                /* TEncGOP / TComPic::compressMotion path: references are padded */
+  g_refpic->getSlice(0)->setPOC(0);
+  g_slice->setSliceType(P_SLICE); g_slice->setPOC(1);
+  g_slice->setNumRefIdx(REF_PIC_LIST_0, 1); g_slice->setNumRefIdx(REF_PIC_LIST_1, 0);
+  g_slice->setRefPic(g_refpic, REF_PIC_LIST_0, 0);
+  g_slice->setRefPOCList();
+  g_slice->setEnableTMVPFlag(false);
+  g_slice->setMaxNumMergeCand(5);
+  const int qpc = (int)g_aucChromaScale[CHROMA_420][g_qp];
+  const double w = pow(2.0, (g_qp - qpc) / 3.0);
+  g_rd->setLambda(lambda);
+  g_rd->setDistortionWeight(COMPONENT_Cb, w); g_rd->setDistortionWeight(COMPONENT_Cr, w);
+  double lambdas[3] = { lambda, lambda / w, lambda / w };
+  g_trq->setLambdas(lambdas);
+  return 0;
+}
+/* inter fields of a decided CTU: skip flags, inter direction, list-0 motion */
+void ref_set_ctu_inter(int ctu, const unsigned char *skip, const unsigned char *interDir, const unsigned char *mergeFlag, const short *mv, const signed char *refIdx)
+{
+  TComDataCU *c = g_pic->getCtu(ctu);
+  TComCUMvField *f = c->getCUMvField(REF_PIC_LIST_0);
+  for (int i = 0; i < 256; i++) {
+    c->getSkipFlag()[i] = skip[i] != 0; c->getInterDir()[i] = interDir[i]; c->getMergeFlag()[i] = mergeFlag[i] != 0;
+    f->m_pcMv[i].set(mv[2 * i], mv[2 * i + 1]); f->m_piRefIdx[i] = refIdx[i];
+  }
+}
+/* One inter candidate through the reference: the body of TEncCu::xCheckRDCostInter (TEncCu.cpp:2025-2062) */
+int ref_inter_cu(int ctu, int zidx, int depth, int partSize, RefCuOut *out)
+{
+  TComDataCU *cu = position_cu(ctu, zidx, depth);
+  entropy_to_goon();
+  g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);
+  g_yOrg[depth]->copyFromPicYuv(g_pic->getPicYuvOrg(), ctu, zidx);
+  cu->setPartSizeSubParts(PartSize(partSize), 0, depth);
+  cu->setPredModeSubParts(MODE_INTER, 0, depth);
+  cu->setChromaQpAdjSubParts(0, 0, depth);
+  cu->setMergeAMP(true);
+  g_search->predInterSearch(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], false, false);
+  g_search->encodeResAndCalcRdInterCU(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yResiBest[depth], g_yReco[depth], false);
+  cu->getTotalCost() = g_rd->calcRdCost(cu->getTotalBits(), cu->getTotalDistortion());
+  read_cu(cu, depth, out);
+  out->dist_luma = 0;
+  return 0;
+}
+/* One merge candidate, with or without residual: the loop body of TEncCu::xCheckRDCostMerge2Nx2N (TEncCu.cpp:1941-1975).
+ * cands5x3 receives the candidate list (mv hor, mv ver, refIdx) of getInterMergeCandidates. */
+int ref_merge_cu(int ctu, int zidx, int depth, int cand, int noResidual, RefCuOut *out, int *cands5x3)
+{
+  TComDataCU *cu = position_cu(ctu, zidx, depth);
+  entropy_to_goon();
+  g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);
+  g_yOrg[depth]->copyFromPicYuv(g_pic->getPicYuvOrg(), ctu, zidx);
+  TComMvField mvf[2 * MRG_MAX_NUM_CANDS]; UChar dirs[MRG_MAX_NUM_CANDS]; Int numValid = 0;
+  for (UInt ui = 0; ui < cu->getSlice()->getMaxNumMergeCand(); ++ui) dirs[ui] = 0;
+  cu->setPartSizeSubParts(SIZE_2Nx2N, 0, depth);
+  cu->getInterMergeCandidates(0, 0, mvf, dirs, numValid);
+  for (int i = 0; i < 5; i++) { cands5x3[3 * i] = mvf[2 * i].getHor(); cands5x3[3 * i + 1] = mvf[2 * i].getVer(); cands5x3[3 * i + 2] = mvf[2 * i].getRefIdx(); }
+  if (cand >= numValid) return -1;
+  cu->setPredModeSubParts(MODE_INTER, 0, depth);
+  cu->setCUTransquantBypassSubParts(false, 0, depth);
+  cu->setChromaQpAdjSubParts(0, 0, depth);
+  cu->setPartSizeSubParts(SIZE_2Nx2N, 0, depth);
+  cu->setMergeFlagSubParts(true, 0, 0, depth);
+  cu->setMergeIndexSubParts(cand, 0, 0, depth);
+  cu->setInterDirSubParts(dirs[cand], 0, 0, depth);
+  cu->getCUMvField(REF_PIC_LIST_0)->setAllMvField(mvf[0 + 2 * cand], SIZE_2Nx2N, 0, 0);
+  cu->getCUMvField(REF_PIC_LIST_1)->setAllMvField(mvf[1 + 2 * cand], SIZE_2Nx2N, 0, 0);
+  g_search->motionCompensation(cu, g_yPred[depth]);
+  g_search->encodeResAndCalcRdInterCU(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yResiBest[depth], g_yReco[depth], noResidual != 0);
+  read_cu(cu, depth, out);
+  out->dist_luma = 0;
+  return numValid;
 }
 
 } /* extern "C" */
