@@ -1151,6 +1151,7 @@ int hmo_test_tq(HmoEnc *e, int comp, int log2, int lumaDir, int chromaDir, int t
 {
   const int N = 1 << log2;
   HmoCU *cu = e->temp[0];
+  memset(cu->pred_mode, HMO_MODE_INTRA, HMO_NPART);
   memset(cu->intra_dir[0], lumaDir, HMO_NPART); memset(cu->intra_dir[1], chromaDir, HMO_NPART);
   HmoTU tu; memset(&tu, 0, sizeof(tu)); tu.tr_depth = trDepthRel; tu.log2 = comp ? log2 + 1 : log2;
   int32_t tcoef[32 * 32];
@@ -1168,11 +1169,12 @@ int hmo_test_tq(HmoEnc *e, int comp, int log2, int lumaDir, int chromaDir, int t
 void hmo_test_code_coeff(HmoEnc *e, int comp, int log2, int lumaDir, int chromaDir, int tskip, const int32_t *coef)
 {
   HmoCU *cu = e->temp[0];
+  memset(cu->pred_mode, HMO_MODE_INTRA, HMO_NPART);
   memset(cu->intra_dir[0], lumaDir, HMO_NPART); memset(cu->intra_dir[1], chromaDir, HMO_NPART);
   memset(cu->tskip[comp], tskip, HMO_NPART);
   hmo_code_coeff_nxn(e, cu, coef, log2, comp, 0);
 }
-void hmo_test_cabac_get(const HmoEnc *e, uint8_t *ctx, uint64_t *frac) { memcpy(ctx, e->goon.ctx, HMO_NCTX); *frac = e->goon.frac; }
+void hmo_test_cabac_get(const HmoEnc *e, uint8_t *ctx, uint64_t *frac) { memcpy(ctx, e->goon.ctx, HMO_NCTX_INTRA); *frac = e->goon.frac; }   /* the 160 contexts of the leaf fixtures */
 void hmo_test_reset_bits(HmoEnc *e) { hmo_reset_bits(e); }
 double hmo_test_rd_cost(const HmoEnc *e, uint32_t bits, uint32_t dist) { return calc_rd_cost(e, bits, dist); }
 uint32_t hmo_test_chroma_dist(const HmoEnc *e, uint32_t sse) { return (uint32_t)(e->p.chroma_weight * (double)sse); }

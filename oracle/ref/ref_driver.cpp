@@ -49,10 +49,23 @@
 #include <math.h>
 #include <string.h>
 
+/* Every object of the reference that this driver creates starts from zeroed memory: several reference classes leave
+ * members to their owner (TEncTop::init -- not built -- sets e.g. TComRdCost::m_costMode, the TEncCfg fields), and a
+ * process whose heap has been used before would hand them arbitrary values.  (The version script keeps these operators
+ * local to libhmleaf.so.) */
+void *operator new(std::size_t n) { void *p = calloc(1, n ? n : 1); if (!p) throw std::bad_alloc(); return p; }
+void *operator new[](std::size_t n) { void *p = calloc(1, n ? n : 1); if (!p) throw std::bad_alloc(); return p; }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, std::size_t) noexcept { free(p); }
+void operator delete[](void *p, std::size_t) noexcept { free(p); }
+
 Void xTrMxN(Int bitDepth, TCoeff *block, TCoeff *coeff, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
 Void xITrMxN(Int bitDepth, TCoeff *coeff, TCoeff *block, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
 
-static TComSPS g_sps; static TComPPS g_pps; static TComPic *g_pic = 0; static TComSlice *g_slice = 0;
+/* heap objects that are never destroyed: TComPic::create copies the SPS / PPS (raw pointer members), so static
+ * instances would be freed twice by the exit-time destructors */
+static TComSPS &g_sps = *new TComSPS; static TComPPS &g_pps = *new TComPPS; static TComPic *g_pic = 0; static TComSlice *g_slice = 0;
 static TComPrediction *g_pred = 0; static TComTrQuant *g_trq = 0; static TComRdCost *g_rd = 0;
 static TEncSbac *g_sbac = 0; static TEncBinCABACCounter *g_bin = 0; static TEncEntropy *g_ent = 0; static TComBitCounter *g_bits = 0;
 static int g_qp = 32;
@@ -95,7 +108,7 @@ int ref_setup(int width, int height, int qp)
     c->setPredModeSubParts(MODE_INTRA, 0, 0); c->setPartSizeSubParts(SIZE_2Nx2N, 0, 0);
   }
   g_pred = new TComPrediction(); g_pred->initTempBuff(CHROMA_420);
-  g_rd = new TComRdCost(); g_rd->init();
+  g_rd = new TComRdCost(); g_rd->init(); g_rd->setCostMode(COST_STANDARD_LOSSY);   /* TEncTop::init */
   g_trq = new TComTrQuant(); g_trq->init(32, true, true, true, true, false);
   g_trq->setFlatScalingList(CHROMA_420); g_trq->setUseScalingList(false);
   /* slice lambda as TEncSlice::initEncSlice / setUpLambda do for an I slice */

@@ -53,7 +53,7 @@ def test_reference_and_oracle_agree_live(built, pkg):
     Y, U, V = pkg.synth.mixed(w, h, seed=99)
     enc = hmo_py.Encoder(Y, U, V, qp)
     ref = st.RefSearch(w, h, qp, (Y, U, V))
-    n = [0, 0]
+    n, bad = [0], []
 
     def on_event(ev, depth, arg):
         if ev == hmo_py.EV_INTRA_BEGIN:
@@ -61,9 +61,11 @@ def test_reference_and_oracle_agree_live(built, pkg):
         elif ev == hmo_py.EV_INTRA_END:
             cu = enc.test_cu(depth)
             r = st.record_from_ref(ref.intra_cu(enc.cur_ctu(), cu.zidx, depth, arg), ref, depth, enc.cur_ctu(), cu.zidx, arg)
+            m = st.record_from_oracle(enc, depth, arg)
             n[0] += 1
-            n[1] += not np.array_equal(r, st.record_from_oracle(enc, depth, arg))
+            if not np.array_equal(r, m):
+                bad.append("reference %s\noracle    %s" % (st.fmt(r), st.fmt(m)))
 
     enc.set_trace(on_event)
     enc.compress_frame()
-    assert n[0] > 100 and n[1] == 0
+    assert n[0] > 100 and not bad, "\n".join(bad[:3])
