@@ -6,6 +6,7 @@ Layout:
   engine.py              ctypes binding + `TEncCu`-shaped host class
   synth.py               synthetic YUV generators
   sequence.py            picture-level driver: fast-decision schedule, slices as chains, deblocking, .yuv I/O
+  lowdelay.py            lowdelay_P driver: P pictures referencing the previous filtered reconstruction
 """
-from . import sequence, sharding, synth  # noqa: F401
+from . import lowdelay, sequence, sharding, synth  # noqa: F401
 from .engine import CuEngine, FrameParams, FcuError, lib_path, load_lib  # noqa: F401

@@ -1,5 +1,5 @@
 /*
- * fcu_deblock.h -- in-loop deblocking of a decided all-intra picture on the device
+ * fcu_deblock.h -- in-loop deblocking of a decided intra or P picture on the device
  * (TComLoopFilter::loopFilterPic, Lib/TLibCommon/TComLoopFilter.cpp:130-155; called per picture at TEncGOP.cpp:1160).
  * Included by fcu_kernels.hip only.
  *
@@ -14,7 +14,10 @@
  * Edges 8 samples apart never touch each other's samples (3 modified, 4 read per side), so the threads of a pass are
  * independent and the filter runs in place like the reference's.  Edge flags come straight from the TComDataCU arrays
  * of fcu_ctu_out: the partition on the Q side starts a transform unit there (xSetEdgefilterTU / xSetEdgefilterPU,
- * :270-343), is inside the picture and not on its border (xSetLoopfilterParam, :346-405); intra => Bs 2 (:436-440).
+ * :270-343) or a prediction unit (2NxN / Nx2N halves), is inside the picture and not on its border (xSetLoopfilterParam,
+ * :346-405).  Boundary strength (xGetBoundaryStrengthSingle, :405-553): 2 next to an intra CU; else 1 across a transform
+ * edge with a coded luma block on either side, or across different motion (P slices: one list; |dmv| >= 4 quarter samples
+ * or different reference); else 0.  Chroma is filtered at Bs 2 only.
  * Algorithmic bytes per pass: read 1.5*W*H samples + 4 bytes of CU data per 4x4 partition, write <= 1.5*W*H.
  */
 #pragma once
@@ -55,9 +58,9 @@ __device__ static inline void dbk_line_luma(int m[8], int tc, int sw, int thrCut
   }
 }
 /* the four lines of one luma segment: the loop body of xEdgeFilterLuma (:597-665).  Returns 0 when nothing is filtered. */
-__device__ static inline int dbk_segment_luma(int m[4][8], int qp, int betaOff, int tcOff)
+__device__ static inline int dbk_segment_luma(int m[4][8], int qp, int betaOff, int tcOff, int bs)
 {
-  const int tc = k_dbk_tc[dbk_clip3(0, 53, qp + 2 + tcOff * 2)];           /* Bs 2: + DEFAULT_INTRA_TC_OFFSET * (Bs - 1) */
+  const int tc = k_dbk_tc[dbk_clip3(0, 53, qp + 2 * (bs - 1) + tcOff * 2)];           /* + DEFAULT_INTRA_TC_OFFSET * (Bs - 1) */
   const int beta = k_dbk_beta[dbk_clip3(0, 51, qp + betaOff * 2)];
   const int side = (beta + (beta >> 1)) >> 3, thrCut = tc * 10;
   const int dp0 = dbk_abs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = dbk_abs(m[0][4] - 2 * m[0][5] + m[0][6]);
@@ -90,7 +93,7 @@ __device__ static inline int dbk_zidx(int x4, int y4)
   y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
   return x | (y << 1);
 }
-struct DbkPart { int flag, qp; };
+struct DbkPart { int flag, qp, bs; };
 /* CU data of the partition (x4, y4) (4-sample units of the picture) for direction DIR: is its left / top border a
  * filtered edge, and its QP */
 template <int DIR>
@@ -101,8 +104,21 @@ __device__ static inline DbkPart dbk_part(const fcu_ctu_out *out, int w_ctu, int
   DbkPart r;
   r.qp = c->qp[z];
   const int pos = (DIR == 0 ? x4 : y4) * 4;
-  const int tu = (CTU >> c->depth[z]) >> c->tr_idx[z];
-  r.flag = c->part_size[z] != SIZE_NONE && pos != 0 && (pos & (tu - 1)) == 0;
+  const int cu = CTU >> c->depth[z], tu = cu >> c->tr_idx[z], ps = c->part_size[z];
+  r.flag = 0; r.bs = 0;
+  if (ps == SIZE_NONE || pos == 0) return r;
+  if ((pos & (tu - 1)) == 0) r.flag = 1;                                   /* transform-unit / CU edge */
+  else if ((pos & (cu - 1)) == (cu >> 1) && (ps == SIZE_NxN || (DIR == 0 ? ps == SIZE_Nx2N : ps == SIZE_2NxN))) r.flag = 2;   /* PU edge only */
+  if (!r.flag) return r;
+  /* boundary strength against the partition on the P side */
+  const int px4 = DIR == 0 ? x4 - 1 : x4, py4 = DIR == 0 ? y4 : y4 - 1;
+  const fcu_ctu_out *p = &out[(py4 >> 4) * w_ctu + (px4 >> 4)];
+  const int zp = dbk_zidx(px4, py4);
+  if (p->pred_mode[zp] == MODE_INTRA || c->pred_mode[z] == MODE_INTRA) { r.bs = 2; return r; }
+  if (r.flag == 1 && ((((c->cbf[0][z] >> c->tr_idx[z]) & 1) != 0) || (((p->cbf[0][zp] >> p->tr_idx[zp]) & 1) != 0))) { r.bs = 1; return r; }
+  const int rp = p->ref_idx[zp], rq = c->ref_idx[z];
+  const int mpx = rp < 0 ? 0 : p->mv[zp][0], mpy = rp < 0 ? 0 : p->mv[zp][1], mqx = rq < 0 ? 0 : c->mv[z][0], mqy = rq < 0 ? 0 : c->mv[z][1];
+  r.bs = ((rp < 0) != (rq < 0) || (rp >= 0 && rp != rq) || dbk_abs(mqx - mpx) >= 4 || dbk_abs(mqy - mpy) >= 4) ? 1 : 0;
   return r;
 }
 __device__ static inline int dbk_qp_of(const fcu_ctu_out *out, int w_ctu, int x4, int y4)
@@ -121,7 +137,7 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
     if (y4 >= (h >> 2)) return;
     const int x4 = x8 * 2;
     const DbkPart q = dbk_part<0>(out, w_ctu, x4, y4);
-    if (!q.flag) return;                                       /* includes the picture border x = 0 (:358-365) */
+    if (!q.bs) return;                                         /* no edge here (incl. the picture border x = 0, :358-365) or Bs 0 */
     const int qp = (dbk_qp_of(out, w_ctu, x4 - 1, y4) + q.qp + 1) >> 1;
     int m[4][8];
     uint8_t *p = Y + (size_t)(y4 * 4) * w + x4 * 4 - 4;
@@ -131,14 +147,14 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
 #pragma unroll
       for (int k = 0; k < 4; k++) { m[i][k] = (a >> (8 * k)) & 255; m[i][4 + k] = (b >> (8 * k)) & 255; }
     }
-    if (dbk_segment_luma(m, qp, betaOff, tcOff)) {
+    if (dbk_segment_luma(m, qp, betaOff, tcOff, q.bs)) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         *(uint32_t *)(p + (size_t)i * w) = (uint32_t)m[i][0] | ((uint32_t)m[i][1] << 8) | ((uint32_t)m[i][2] << 16) | ((uint32_t)m[i][3] << 24);
         *(uint32_t *)(p + (size_t)i * w + 4) = (uint32_t)m[i][4] | ((uint32_t)m[i][5] << 8) | ((uint32_t)m[i][6] << 16) | ((uint32_t)m[i][7] << 24);
       }
     }
-    if ((x4 & 3) == 0) {                                       /* 8-sample chroma grid (:216-221,700-707) */
+    if ((x4 & 3) == 0 && q.bs == 2) {                          /* 8-sample chroma grid (:216-221,700-707), intra edges only (:723) */
       const int tc = k_dbk_tc[dbk_clip3(0, 53, (int)k_chroma_scale[qp] + 2 + tcOff * 2)];      /* cb / cr QP offsets 0 (:747-766) */
 #pragma unroll
       for (int comp = 0; comp < 2; comp++) {
@@ -163,7 +179,7 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
 #pragma unroll
     for (int k = 0; k < 8; k++) ra[k] = *(const uint32_t *)(p + (size_t)k * w);
     const DbkPart q = dbk_part<1>(out, w_ctu, x4, y4);
-    if (!q.flag) return;
+    if (!q.bs) return;
     const int qp = (dbk_qp_of(out, w_ctu, x4, y4 - 1) + q.qp + 1) >> 1;
     int m[4][8];
 #pragma unroll
@@ -171,12 +187,12 @@ dbk_pass(const fcu_ctu_out *out, uint8_t *Y, uint8_t *U, uint8_t *V, int w, int 
 #pragma unroll
       for (int i = 0; i < 4; i++) m[i][k] = (ra[k] >> (8 * i)) & 255;
     }
-    if (dbk_segment_luma(m, qp, betaOff, tcOff)) {
+    if (dbk_segment_luma(m, qp, betaOff, tcOff, q.bs)) {
 #pragma unroll
       for (int k = 1; k < 7; k++)
         *(uint32_t *)(p + (size_t)k * w) = (uint32_t)m[0][k] | ((uint32_t)m[1][k] << 8) | ((uint32_t)m[2][k] << 16) | ((uint32_t)m[3][k] << 24);
     }
-    if ((y4 & 3) == 0) {
+    if ((y4 & 3) == 0 && q.bs == 2) {
       const int tc = k_dbk_tc[dbk_clip3(0, 53, (int)k_chroma_scale[qp] + 2 + tcOff * 2)];
 #pragma unroll
       for (int comp = 0; comp < 2; comp++) {

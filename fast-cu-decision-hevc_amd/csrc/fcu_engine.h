@@ -37,6 +37,9 @@
 #define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
 #define FCU_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
+/* wave reductions of per-lane partial results into one LDS word (all 64 lanes call them, outside divergent code) */
+#define FCU_WAVE_ADD(p, v) (*(p) += (v))
+#define FCU_WAVE_MIN64(p, v) do { if ((v) < *(p)) *(p) = (v); } while (0)
 #define FCU_IN_LDS(p) do { } while (0)
 #define FCU_UNI(x) (x)
 #define FCU_HBM
@@ -50,6 +53,20 @@
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define FCU_ATOMIC_MAX(p, v) atomicMax((p), (v))
+/* wave reductions: cross-lane butterfly (ds_swizzle / DPP through __shfl_xor), then ONE lane touches LDS -- the
+ * SAD / SSE / Hadamard partial sums of the inter path (north star: "wavefront __shfl reductions for per-PU costs") */
+__device__ inline uint32_t fcu_wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o); return v; }
+__device__ inline unsigned long long fcu_wave_min64(unsigned long long v)
+{
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w < v ? w : v;
+  }
+  return v;
+}
+#define FCU_WAVE_ADD(p, v) do { const uint32_t s_ = fcu_wave_sum(v); if (threadIdx.x == 0) *(p) += s_; } while (0)
+#define FCU_WAVE_MIN64(p, v) do { const unsigned long long s_ = fcu_wave_min64(v); if (threadIdx.x == 0 && s_ < *(p)) *(p) = s_; } while (0)
 /* address-space fact for a pointer that crossed a call boundary (lets the compiler emit ds_ instead of flat_ accesses) */
 /* wave-uniform value -> scalar registers.  Everything the orchestration code passes around (chain/scratch/CU
  * pointers, TU descriptors, depths) is the same in all lanes; saying so keeps it in SGPRs, turns the control
@@ -141,6 +158,9 @@ struct Params {
   double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
   double err_scale[2][4];     /* [luma/chroma][log2-2]   setErrScaleCoeff, TComTrQuant.cpp:3018-3040 */
   long long rd_factor[2];     /* sign-hiding rdFactor,   TComTrQuant.cpp:2444-2447 */
+  /* P slices (BASELINE configs[4]) */
+  int search_range, fast_enc, had_me, fdm, max_merge_cand;
+  uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
 };
 
 /* per-chain descriptor in HBM */
@@ -148,6 +168,10 @@ struct Chain {
   const uint8_t *org[3];
   uint8_t *rec[3];
   int stride[3];
+  /* P slice: reference picture (list 0, index 0), padded planes: ref[c] points at sample (0,0), the border is
+   * replicated FCU_REF_MARGIN (>> 1 for chroma) samples to every side (TComPicYuv::extendPicBorder) */
+  const uint8_t *ref[3];
+  int ref_stride[3];
   fcu_ctu_out *out;
   Params p;
   int w_ctu, h_ctu, n_ctu;
@@ -169,9 +193,13 @@ struct CuObj {
   int depth_cu, x, y, zidx, nparts;
   uint8_t depth[NPART]; int8_t part_size[NPART], pred_mode[NPART]; uint8_t tr_idx[NPART];
   uint8_t tskip[3][NPART], cbf[3][NPART], intra_dir[2][NPART];
+  uint8_t skip[NPART], merge_flag[NPART], merge_idx[NPART], inter_dir[NPART]; int8_t mvp_idx[NPART], ref_idx[NPART];
+  int16_t mv[NPART][2], mvd[NPART][2];
   alignas(16) int16_t coef[3][CTU * CTU];
 };
+struct Yuv16 { int16_t y[64 * 64], u[32 * 32], v[32 * 32]; };
 struct Yuv { uint8_t y[64 * 64], u[32 * 32], v[32 * 32]; };
+enum { FCU_REF_MARGIN = 80 };                     /* luma border of a reference picture: g_uiMaxCUWidth + 16 (TComPic::create) */
 /* state of one chroma-mode trial: the mode's own reconstruction (overlay of PicYuvRec inside the CU), levels, flags */
 struct ChromaModeBuf { uint8_t u[32 * 32], v[32 * 32]; alignas(16) int16_t coef[2][1024]; uint8_t cbf[2][NPART], tskip[2][NPART]; };
 
@@ -197,6 +225,11 @@ struct alignas(16) Scratch {
   /* 64x64 first pass: per-candidate reconstruction and levels of the whole PU (candidates advance side by side) */
   uint8_t c64_rec[5][CTU * CTU]; alignas(16) int16_t c64_coef[5][CTU * CTU];
   Cabac c64_state[5][4]; uint32_t c64_distk[5][4];   /* ... and its coder / distortion after each of the four TUs */
+  /* inter: residual of the CU, chosen residual, residual per RQT layer (m_pcQTTempTComYuv holds residuals here), m_tmpYuvPred,
+   * the nine interpolated blocks of a fractional refinement round */
+  Yuv16 resi_cu, resi_best, qt_resi[4];
+  Yuv tmp_pred;
+  uint8_t me_pred[9][CTU * CTU];
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
@@ -229,9 +262,22 @@ struct Shared {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
     int uni[8];                                                       /* chroma leaf: transform-skip choice per mode */
   };
-  uint32_t est[NCTX_INTRA * 2];                            /* estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
-  uint8_t vc_slot[MAXVC];                           /* lane coder that holds a variant's state after the bit count */
-  int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
+  uint32_t est[NCTX_INTRA * 2];                      /* [159] (the pad context) carries rqt_root_cbf for inter luma; estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
+  union {                                           /* intra candidate batch / inter mailboxes: never live at the same time */
+    struct {
+      uint8_t vc_slot[MAXVC];                       /* lane coder that holds a variant's state after the bit count */
+      int vc_abs[MAXVC], vc_lsp[MAXVC], vc_last[MAXVC]; uint32_t vc_dist[MAXVC]; uint32_t vc_bits[MAXVC]; double vc_cost[MAXVC];   /* chroma uses [10..14] of vc_dist */
+    };
+    struct {
+      uint32_t acc[16];                             /* wave-reduced sums (SAD / SSE / Hadamard per candidate or variant) */
+      unsigned long long me_best;                   /* (cost << 32) | raster index of the best integer position */
+      int mrg_mv[5][2], mrg_ref[5], amvp[2][2];     /* merge candidates, AMVP candidates of the PU being searched */
+      int iv_abs[6], iv_lsp[6], iv_top[6]; uint32_t iv_dist[6], iv_bits[6];   /* inter TU variants: Y, Y-ts, Cb, Cb-ts, Cr, Cr-ts */
+      int it_abs[3], it_ts[3]; uint32_t it_dist[3]; /* chosen variant per component */
+      double iq_cost[5]; uint32_t iq_bits[5], iq_dist[5], iq_zero;   /* xEstimateInterResidualQT accumulators per recursion level */
+      int mrg_buf[5], best_is_skip, me_out[4];      /* xCheckRDCostMerge2Nx2N bookkeeping; motion_estimation results (mvx, mvy) */
+    };
+  };
   int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
   int t_abs, t_lsp, t_last; uint32_t t_dist;
@@ -350,7 +396,8 @@ FCU_DEV uint32_t cab_bits(int cid) { return (uint32_t)(FCU_CB.frac >> 15); }
 FCU_DEV int ctx_bits(int cid, int ctx, int bin) { return (int)(g_hot.bin[FCU_CB.ctx[ctx] * 2 + bin] >> 8); }
 /* TEncSbac::estBit: the costs of both bins of every context of coder `cid`, one LDS word each; called by all lanes
  * in the phase before RDOQ (the contexts are frozen while RDOQ runs) */
-FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX_INTRA * 2; i += 64) g_S.est[i] = g_hot.bin[FCU_CB.ctx[i >> 1] * 2 + (i & 1)] >> 8; }
+enum { EST_ROOT_CBF = NCTX_INTRA - 1 };
+FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX_INTRA * 2; i += 64) { const int cx = (i >> 1) == EST_ROOT_CBF ? CTX_ROOT_CBF : (i >> 1); g_S.est[i] = g_hot.bin[FCU_CB.ctx[cx] * 2 + (i & 1)] >> 8; } }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -1098,6 +1145,8 @@ FCU_DEV int min_tu_log2_in_cu(int depth, int partSize)      /* getQuadtreeTULog2
   return m > LOG2_MAXTU ? LOG2_MAXTU : m;
 }
 
+#include "fcu_inter.h"
+
 /* ---- syntax element coders (serial, any Cabac) ------------------------------------------ */
 FCU_DEV void code_split_flag(const Env E, int c, const CuObj *cu, int part, int depth)   /* TEncSbac.cpp:613-628 */
 {
@@ -1191,6 +1240,7 @@ FCU_DEV FCU_NOINLINE void enc_coeff_qt(int c, const CuObj *cu, uint32_t root_k, 
 FCU_DEV void enc_intra_header(const Env E, int c, const CuObj *cu, int trDepth, int part, int bLuma, int bChroma)
 {
   if (bLuma) {
+    if (part == 0 && E.C->p.slice_type != SLICE_I) { code_skip_flag(E, c, cu, 0); code_pred_mode(c, cu, 0); }   /* TEncSearch.cpp:990-1000 */
     if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, cu->part_size[0] == SIZE_2Nx2N, CTX_PARTSIZE);
     if (cu->part_size[0] == SIZE_2Nx2N) { if (part == 0) code_intra_dir_luma(c, cu, 0, 0); }
     else { const int q = cu->nparts >> 2; if (trDepth > 0 && (part & (q - 1)) == 0) code_intra_dir_luma(c, cu, part, 0); }
@@ -1216,6 +1266,7 @@ FCU_DEV FCU_NOINLINE uint32_t leaf_luma_bits(int c, const CuObj *cu, uint32_t tu
   const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k));
   const int part = tu.part, partSize = cu->part_size[0], log2 = tu.log2;
   cab_reset_bits(c);
+  if (part == 0 && E.C->p.slice_type != SLICE_I) { code_skip_flag(E, c, cu, 0); code_pred_mode(c, cu, 0); }
   if (part == 0 && cu->depth[0] == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
   if (partSize == SIZE_2Nx2N ? (part == 0) : (tu.tr_depth > 0 && (part & ((cu->nparts >> 2) - 1)) == 0))
     code_luma_dir_bits(c, cu->intra_dir[0][part], g_S.preds);
@@ -1269,6 +1320,10 @@ FCU_DEV FCU_NOINLINE void encode_transform(int c, const CuObj *cu, int cuPart, u
 }
 FCU_DEV void encode_cu_syntax(const Env E, int c, const CuObj *cu, int cuPart, int depth)   /* TEncCu.cpp:2117-2141 / 1753-1778 */
 {
+  if (E.C->p.slice_type != SLICE_I) {                        /* encodeSkipFlag / encodePredMode are no-ops in I slices */
+    if (cu->pred_mode[cuPart] == MODE_INTER) { encode_cu_syntax_inter(E, c, cu, cuPart, depth); return; }
+    code_skip_flag(E, c, cu, cuPart); code_pred_mode(c, cu, cuPart);
+  }
   if (depth == MAXDEPTH) cab_bin(c, cu->part_size[cuPart] == SIZE_2Nx2N, CTX_PARTSIZE);
   code_intra_dir_luma(c, cu, cuPart, 1);
   code_intra_dir_chroma(c, cu->intra_dir[1][cuPart]);
@@ -1289,6 +1344,8 @@ FCU_DEV FCU_NOINLINE void cu_init(CuObj *cu, int depth, int x, int y, int zidx) 
       cu->depth[i] = (uint8_t)depth; cu->part_size[i] = SIZE_NONE; cu->pred_mode[i] = MODE_NONE; cu->tr_idx[i] = 0;
       cu->tskip[0][i] = cu->tskip[1][i] = cu->tskip[2][i] = 0; cu->cbf[0][i] = cu->cbf[1][i] = cu->cbf[2][i] = 0;
       cu->intra_dir[0][i] = DC; cu->intra_dir[1][i] = 0;
+      cu->skip[i] = 0; cu->merge_flag[i] = 0; cu->merge_idx[i] = 0; cu->inter_dir[i] = 0; cu->mvp_idx[i] = -1; cu->ref_idx[i] = -1;
+      cu->mv[i][0] = cu->mv[i][1] = 0; cu->mvd[i][0] = cu->mvd[i][1] = 0;
     }
     for (int i = lane; i < s * s; i += 64) cu->coef[0][i] = 0;
     for (int i = lane; i < s * s / 4; i += 64) { cu->coef[1][i] = 0; cu->coef[2][i] = 0; }
@@ -1306,6 +1363,9 @@ FCU_DEV FCU_NOINLINE void cu_copy_part_from(CuObj *dst, const CuObj *src, int pa
       dst->tr_idx[off + i] = src->tr_idx[i];
       for (int c = 0; c < 3; c++) { dst->tskip[c][off + i] = src->tskip[c][i]; dst->cbf[c][off + i] = src->cbf[c][i]; }
       dst->intra_dir[0][off + i] = src->intra_dir[0][i]; dst->intra_dir[1][off + i] = src->intra_dir[1][i];
+      dst->skip[off + i] = src->skip[i]; dst->merge_flag[off + i] = src->merge_flag[i]; dst->merge_idx[off + i] = src->merge_idx[i];
+      dst->inter_dir[off + i] = src->inter_dir[i]; dst->mvp_idx[off + i] = src->mvp_idx[i]; dst->ref_idx[off + i] = src->ref_idx[i];
+      dst->mv[off + i][0] = src->mv[i][0]; dst->mv[off + i][1] = src->mv[i][1]; dst->mvd[off + i][0] = src->mvd[i][0]; dst->mvd[off + i][1] = src->mvd[i][1];
     }
     for (int i = lane; i < n * 16; i += 64) dst->coef[0][off * 16 + i] = src->coef[0][i];
     for (int i = lane; i < n * 4; i += 64) { dst->coef[1][off * 4 + i] = src->coef[1][i]; dst->coef[2][off * 4 + i] = src->coef[2][i]; }
@@ -1320,7 +1380,10 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                       
   FCU_FOR_LANES {
     if (lane == 0) { p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins; }
     for (int i = lane; i < n; i += 64) {
-      p->depth[off + i] = cu->depth[i]; p->width[off + i] = (uint8_t)s; p->height[off + i] = (uint8_t)s; p->skip[off + i] = 0;
+      p->depth[off + i] = cu->depth[i]; p->width[off + i] = (uint8_t)s; p->height[off + i] = (uint8_t)s; p->skip[off + i] = cu->skip[i];
+      p->merge_flag[off + i] = cu->merge_flag[i]; p->merge_idx[off + i] = cu->merge_idx[i]; p->inter_dir[off + i] = cu->inter_dir[i];
+      p->mvp_idx[off + i] = cu->mvp_idx[i]; p->ref_idx[off + i] = cu->ref_idx[i];
+      p->mv[off + i][0] = cu->mv[i][0]; p->mv[off + i][1] = cu->mv[i][1]; p->mvd[off + i][0] = cu->mvd[i][0]; p->mvd[off + i][1] = cu->mvd[i][1];
       p->part_size[off + i] = cu->part_size[i]; p->pred_mode[off + i] = cu->pred_mode[i]; p->qp[off + i] = (int8_t)qp;
       p->tr_idx[off + i] = cu->tr_idx[i];
       for (int c = 0; c < 3; c++) { p->tskip[c][off + i] = cu->tskip[c][i]; p->cbf[c][off + i] = cu->cbf[c][i]; }
@@ -1331,19 +1394,19 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                       
     if (cu->depth_cu == 0) {
       for (int i = lane; i < 4096; i += 64) {
         const int part = i >> 4; int v = 0;
-        if (cu->pred_mode[part] == MODE_INTRA) {
+        if (cu->pred_mode[part] != MODE_NONE) {
           const int log2 = 6 - cu->depth[part] - cu->tr_idx[part], np = 1 << (2 * (log2 - 2)), tp = part & ~(np - 1);
-          const int st = coef_scan_idx(cu->intra_dir[0][tp], log2, 0);
+          const int st = cu->pred_mode[part] == MODE_INTRA ? coef_scan_idx(cu->intra_dir[0][tp], log2, 0) : 0;   /* inter: SCAN_DIAG */
           v = cu->coef[0][tp * 16 + k_iscan[k_scan_off[st * 4 + log2 - 2] + (i - tp * 16)]];
         }
         p->coeff_y[i] = v;
       }
       for (int i = lane; i < 1024; i += 64) {
         const int part = i >> 2; int vb = 0, vr = 0;
-        if (cu->pred_mode[part] == MODE_INTRA) {
+        if (cu->pred_mode[part] != MODE_NONE) {
           const int ll = 6 - cu->depth[part] - cu->tr_idx[part];            /* luma TU; chroma is half of it, 4x4 covers four luma 4x4 */
           const int log2 = ll > 2 ? ll - 1 : 2, np = ll > 2 ? 1 << (2 * (ll - 2)) : 4, tp = part & ~(np - 1);
-          const int mode = chroma_final_mode(cu, tp), o = k_scan_off[coef_scan_idx(mode, log2, 1) * 4 + log2 - 2];
+          const int mode = chroma_final_mode(cu, tp), o = k_scan_off[(cu->pred_mode[part] == MODE_INTRA ? coef_scan_idx(mode, log2, 1) : 0) * 4 + log2 - 2];
           const int sp = k_iscan[o + (i - tp * 4)];
           vb = cu->coef[1][tp * 4 + sp]; vr = cu->coef[2][tp * 4 + sp];
         }
@@ -1862,6 +1925,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
           const int c = CAB_LANE0 + slot;
           cab_copy1(&g_S.cab[c], slot_ptr(E, d, CI_CURR_BEST));
           cab_reset_bits(c);
+          if (part == 0 && P.slice_type != SLICE_I) { code_skip_flag(E, c, cu, 0); code_pred_mode(c, cu, 0); }
           if (part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
           code_luma_dir_bits(c, mode, g_S.preds);
           if (!(partSize == SIZE_NxN && tu.tr_depth == 0) && log2 <= LOG2_MAXTU && log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize))
@@ -1987,6 +2051,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
     FCU_FOR_LANES {                                          /* the TU's walk (leaf_luma_bits) on the candidate's running coder */
       if (lane < nc) {
         const int c = CAB_LANE0 + lane, mode = g_S.rd_mode[lane], cbf = g_S.vc_abs[lane] > 0;
+        if (tu.part == 0 && P.slice_type != SLICE_I) { code_skip_flag(E, c, cu, 0); code_pred_mode(c, cu, 0); }
         if (tu.part == 0 && d == MAXDEPTH) cab_bin(c, partSize == SIZE_2Nx2N, CTX_PARTSIZE);
         if (tu.part == 0) code_luma_dir_bits(c, mode, g_S.preds);
         if (log2 != LOG2_MINTU && log2 != min_tu_log2_in_cu(d, partSize)) cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
@@ -2435,6 +2500,47 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(int d, int partSize)
   check_best_mode(d);
 }
 
+/* xCheckRDCostInter, TEncCu.cpp:2025-2062 */
+FCU_DEV FCU_NOINLINE void check_rd_cost_inter(int d, int partSize)
+{
+  const Env E = env_get(); d = FCU_UNI(d); partSize = FCU_UNI(partSize);
+  CuObj *cu = cu_temp(E, d);
+  const int n = cu->nparts;
+  FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTER; } }
+  pred_inter_search(cu, partSize);
+  encode_res_and_calc_rd_inter_cu(cu, 0);
+  check_best_mode(d);
+}
+/* xCheckRDCostMerge2Nx2N, TEncCu.cpp:1900-2018 (early skip detection off) */
+FCU_DEV FCU_NOINLINE void check_rd_cost_merge_2nx2n(int d)
+{
+  const Env E = env_get(); d = FCU_UNI(d);
+  Scratch *G = E.G; const Params &P = E.C->p;
+  const CuObj *t0 = cu_temp(E, d);
+  const int x = t0->x, y = t0->y, zidx = t0->zidx, n = t0->nparts;
+  FCU_FOR_LANES { CuObj *cu = cu_temp(E, d); for (int i = lane; i < n; i += 64) cu->part_size[i] = SIZE_2Nx2N; if (lane < 5) g_S.mrg_buf[lane] = 0; if (lane == 0) g_S.best_is_skip = 0; }
+  FCU_SERIAL merge_candidates(cu_temp(E, d), SIZE_2Nx2N, 0);
+  int cmv[5][2], cref[5];
+  for (int c = 0; c < 5; c++) { cmv[c][0] = FCU_UNI(g_S.mrg_mv[c][0]); cmv[c][1] = FCU_UNI(g_S.mrg_mv[c][1]); cref[c] = FCU_UNI(g_S.mrg_ref[c]); }
+  const int nc = P.max_merge_cand;
+  for (int noRes = 0; noRes < 2; noRes++)
+    for (int c = 0; c < nc; c++) {
+      if (noRes == 1 && FCU_UNI(g_S.mrg_buf[c]) == 1) continue;
+      if (FCU_UNI(g_S.best_is_skip) && noRes == 0) continue;
+      CuObj *cu = cu_temp(E, d);
+      FCU_FOR_LANES {
+        for (int i = lane; i < n; i += 64) { cu->pred_mode[i] = MODE_INTER; cu->part_size[i] = SIZE_2Nx2N; }
+        pu_set_motion(cu, SIZE_2Nx2N, 0, lane, cmv[c][0], cmv[c][1], cref[c]); pu_set_info(cu, SIZE_2Nx2N, 0, lane, 1, c, 0, 0, -1);
+      }
+      mc_pu(cu, SIZE_2Nx2N, 0, &G->predt[d], 0);
+      encode_res_and_calc_rd_inter_cu(cu, noRes);
+      FCU_SERIAL { if (noRes == 0 && !qt_root_cbf(cu, 0)) g_S.mrg_buf[c] = 1; }
+      check_best_mode(d);
+      cu_init(cu_temp(E, d), d, x, y, zidx);
+      FCU_SERIAL { if (P.fdm && !g_S.best_is_skip) g_S.best_is_skip = !qt_root_cbf(cu_best(E, d), 0); }
+    }
+}
+
 /* fork hooks of xCompressCU for its default control (YSGlobalControl, tools_YS.cpp:4-58: Naive model on N_OBF).
  * Num_OBF = 4x4 blocks of the CU with a positive OBF count (TEncCu.cpp:585-600); the Naive label is Skip2Nx2N when
  * there is one, TerminateCU when there is none (tools_YS.cpp:686-695, TEncCu.cpp:670-678). */
@@ -2486,9 +2592,19 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       }
     }
     cu_init(cu_temp(E, D), D, x, y, zidx);
-    if (!skip2Nx2N) check_rd_cost_intra(D, SIZE_2Nx2N);      /* :1040; skipped => the best cost stays MAX_DOUBLE (:1077) */
+    int tryIntra = 1;
+    if (P.slice_type == SLICE_P) {                           /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
+      check_rd_cost_merge_2nx2n(D);
+      cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_2Nx2N); cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_Nx2N); cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_2NxN); cu_init(cu_temp(E, D), D, x, y, zidx);
+      const CuObj *b = cu_best(E, D);                          /* intra only when the best inter candidate has a residual (:1033-1036) */
+      tryIntra = FCU_UNI((int)(b->cbf[0][0] | b->cbf[1][0] | b->cbf[2][0])) != 0;
+    }
+    if (!skip2Nx2N && tryIntra) check_rd_cost_intra(D, SIZE_2Nx2N);      /* :1040; skipped => the best cost stays MAX_DOUBLE (:1077) */
     cu_init(cu_temp(E, D), D, x, y, zidx);
-    if (D == MAXDEPTH && !earlyTerminate) {                  /* :1141-1143 */
+    if (D == MAXDEPTH && !earlyTerminate && tryIntra) {      /* :1141-1143 */
       FCU_SERIAL { g_S.dec_j0 = cu_best(E, D)->cost; g_S.dec_flip = g_S.best_idx[D]; }
       check_rd_cost_intra(D, SIZE_NxN);
       FCU_SERIAL { g_S.dec_flip ^= g_S.best_idx[D]; g_S.dec_j1 = g_S.dec_flip ? cu_best(E, D)->cost : cu_temp(E, D)->cost; }   /* :1175-1183 */

@@ -13,6 +13,8 @@ namespace fcu {
 inline void fill_params(Params &p, int width, int height, const fcu_frame_params &fp)
 {
   p.width = width; p.height = height; p.qp = fp.qp; p.slice_ctus = fp.slice_ctus;
+  p.slice_type = fp.slice_type; p.search_range = fp.search_range; p.fast_enc = fp.fast_enc; p.had_me = fp.hadamard_me;
+  p.fdm = fp.fast_merge_decision; p.max_merge_cand = fp.max_merge_cand > 0 ? (fp.max_merge_cand > 5 ? 5 : fp.max_merge_cand) : 5;
   p.transform_skip = fp.transform_skip; p.ts_fast = fp.transform_skip_fast;
   p.sign_hiding = fp.sign_hiding; p.strong_smoothing = fp.strong_intra_smoothing;
   /* chroma QP: g_aucChromaScale[CHROMA_420] (TLibCommon/TComRom.cpp:507), offsets 0 */
@@ -21,8 +23,11 @@ inline void fill_params(Params &p, int width, int height, const fcu_frame_params
     29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
   p.qp_c = fp.qp < 0 ? fp.qp : chroma_scale[fp.qp > 57 ? 57 : fp.qp];
   if (fp.lambda > 0.0) {
-    p.lambda = fp.lambda; p.sqrt_lambda = fp.sqrt_lambda; p.chroma_weight = fp.chroma_weight;
-    for (int i = 0; i < 3; i++) p.rdoq_lambda[i] = fp.rdoq_lambda[i];
+    const double w = fp.chroma_weight > 0.0 ? fp.chroma_weight : pow(2.0, (fp.qp - p.qp_c) / 3.0);     /* setUpLambda, TEncSlice.cpp:496-524 */
+    p.lambda = fp.lambda; p.sqrt_lambda = fp.sqrt_lambda > 0.0 ? fp.sqrt_lambda : sqrt(fp.lambda); p.chroma_weight = w;
+    p.rdoq_lambda[0] = fp.rdoq_lambda[0] > 0.0 ? fp.rdoq_lambda[0] : fp.lambda;
+    p.rdoq_lambda[1] = fp.rdoq_lambda[1] > 0.0 ? fp.rdoq_lambda[1] : fp.lambda / w;
+    p.rdoq_lambda[2] = fp.rdoq_lambda[2] > 0.0 ? fp.rdoq_lambda[2] : fp.lambda / w;
   } else {
     /* TEncSlice::initEncSlice, I slice: lambda = 0.57 * 2^((QP-12)/3)  (TEncSlice.cpp:686-706) */
     const double lambda = 0.57 * pow(2.0, ((double)fp.qp - 12) / 3.0);
@@ -30,6 +35,7 @@ inline void fill_params(Params &p, int width, int height, const fcu_frame_params
     p.lambda = lambda; p.sqrt_lambda = sqrt(lambda); p.chroma_weight = w;
     p.rdoq_lambda[0] = lambda; p.rdoq_lambda[1] = lambda / w; p.rdoq_lambda[2] = lambda / w;
   }
+  p.lambda_motion_sad = (uint32_t)floor(65536.0 * sqrt(p.lambda));      /* TComRdCost::setLambda, TComRdCost.cpp:194-219 */
   for (int ch = 0; ch < 2; ch++) {
     const int qp = ch ? p.qp_c : p.qp, per = qp / 6, rem = qp % 6;
     static const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };
@@ -53,6 +59,21 @@ inline void default_frame_params(fcu_frame_params &fp, int qp)
 {
   memset(&fp, 0, sizeof(fp));
   fp.qp = qp; fp.slice_ctus = 0; fp.transform_skip = 1; fp.transform_skip_fast = 1; fp.sign_hiding = 1; fp.strong_intra_smoothing = 1;
+  fp.slice_type = FCU_SLICE_I; fp.search_range = 64; fp.fast_enc = 1; fp.hadamard_me = 1; fp.fast_merge_decision = 1; fp.max_merge_cand = 5;
+}
+/* TEncSlice::initEncSlice for HM's lowdelay_P GOP table (GOPSize 4): slice type, QP = base + offset, lambda =
+ * QPFactor * 2^((QP-12)/3), x Clip3(2, 4, (QP-12)/6) at temporal depth > 0 (POC % 4 != 0); the I picture's factor is
+ * 0.57 * (1 - 0.05 * (GOPSize - 1)) (TEncSlice.cpp:560-740) */
+inline void ldp_slice(fcu_frame_params &fp, int base_qp, int poc)
+{
+  static const int qp_off[4] = { 3, 2, 3, 1 };
+  static const double qp_fac[4] = { 0.4624, 0.4624, 0.4624, 0.578 };
+  default_frame_params(fp, base_qp);
+  if (poc == 0) { fp.lambda = 0.57 * (1.0 - 0.05 * 3) * pow(2.0, ((double)base_qp - 12) / 3.0); return; }
+  const int g = (poc - 1) % 4, qp = base_qp + qp_off[g];
+  double lambda = qp_fac[g] * pow(2.0, ((double)qp - 12) / 3.0);
+  if (poc % 4 != 0) { double f = ((double)qp - 12) / 6.0; f = f < 2.0 ? 2.0 : (f > 4.0 ? 4.0 : f); lambda *= f; }
+  fp.slice_type = FCU_SLICE_P; fp.qp = qp; fp.lambda = lambda;
 }
 
 } // namespace fcu

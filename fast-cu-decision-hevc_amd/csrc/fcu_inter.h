@@ -1,0 +1,846 @@
+/*
+ * fcu_inter.h -- the P-slice half of the CTU engine (BASELINE configs[4]); included by fcu_engine.h inside namespace fcu.
+ *
+ * Configuration built: one reference picture (list 0 = the previous picture after the loop filters,
+ * padded planes), TMVP off, AMP off, full integer search (FastSearch 0) with FEN sub-sampling, half / quarter refinement
+ * on Hadamard cost, FDM, MaxNumMergeCand 5, QuadtreeTUMaxDepthInter 3.  Replaces, per routine (paths in the reference):
+ *   TEncCu::xCheckRDCostMerge2Nx2N / xCheckRDCostInter                     TEncCu.cpp:1900-2062
+ *   TEncSearch::predInterSearch, xEstimateMvPredAMVP, xMotionEstimation,
+ *     xPatternSearch, xPatternSearchFracDIF, xCheckBestMVP, xMergeEstimation TEncSearch.cpp:2905-4375
+ *   TEncSearch::encodeResAndCalcRdInterCU, xEstimateInterResidualQT,
+ *     xEncodeInterResidualQT, xSetInterResidualQTData, xAddSymbolBitsInter TEncSearch.cpp:4380-5421
+ *   TComDataCU::getInterMergeCandidates, fillMvpCand, clipMv               TComDataCU.cpp:2340-2942
+ *   TComPrediction::motionCompensation + TComInterpolationFilter            TComPrediction.cpp:518-705
+ *   TComRdCost::xGetSAD* / getCost / xGetComponentBits                     TComRdCost.cpp:278-292,465-964, TComRdCost.h:163-189
+ *
+ * How the wave is used: the integer search puts one CANDIDATE POSITION per lane (packed 4-sample SADs, v_sad_u8) and
+ * picks the winner with a cross-lane min; interpolation, Hadamard, SSE and the transforms spread samples over lanes and
+ * reduce with cross-lane sums (FCU_WAVE_ADD); the Y / Cb / Cr (x transform-skip) trials of a transform unit all restart
+ * from the same CABAC snapshot, so their RDOQ and bit counts run side by side, one variant per lane.
+ */
+
+struct Pu { int addr, ox, oy, w, h; };
+FCU_DEV int pu_count(int ps) { return ps == SIZE_2Nx2N ? 1 : (ps == SIZE_NxN ? 4 : 2); }
+FCU_DEV Pu pu_geom(int depth, int ps, int pu)                  /* getPartIndexAndSize / getPartPosition */
+{
+  const int s = CTU >> depth, n = NPART >> (2 * depth);
+  Pu g; g.addr = 0; g.ox = 0; g.oy = 0; g.w = s; g.h = s;
+  if (ps == SIZE_2NxN) { g.h = s >> 1; if (pu) { g.addr = n >> 1; g.oy = s >> 1; } }
+  else if (ps == SIZE_Nx2N) { g.w = s >> 1; if (pu) { g.addr = n >> 2; g.ox = s >> 1; } }
+  else if (ps == SIZE_NxN) { g.w = g.h = s >> 1; g.addr = pu * (n >> 2); g.ox = (pu & 1) * (s >> 1); g.oy = (pu >> 1) * (s >> 1); }
+  return g;
+}
+/* does partition i (relative to the CU, n partitions) belong to prediction unit pu?  (TComCUMvField::setAll / setSubPart) */
+FCU_DEV int pu_covers(int n, int ps, int pu, int i)
+{
+  if (ps == SIZE_2Nx2N) return 1;
+  if (ps == SIZE_2NxN) return (i >= (n >> 1)) == (pu != 0);
+  if (ps == SIZE_Nx2N) return ((i / (n >> 2)) & 1) == pu;
+  return i / (n >> 2) == pu;
+}
+/* motion fields of one PU: all lanes */
+FCU_DEV void pu_set_motion(CuObj *cu, int ps, int pu, int lane, int mvx, int mvy, int ref)
+{ const int n = cu->nparts; for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) { cu->mv[i][0] = (int16_t)mvx; cu->mv[i][1] = (int16_t)mvy; cu->ref_idx[i] = (int8_t)ref; } }
+FCU_DEV void pu_set_info(CuObj *cu, int ps, int pu, int lane, int mergeFlag, int mergeIdx, int mvdx, int mvdy, int mvpIdx)
+{
+  const int n = cu->nparts;
+  for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) {
+    cu->merge_flag[i] = (uint8_t)mergeFlag; cu->merge_idx[i] = (uint8_t)mergeIdx; cu->inter_dir[i] = 1;
+    cu->mvd[i][0] = (int16_t)mvdx; cu->mvd[i][1] = (int16_t)mvdy; cu->mvp_idx[i] = (int8_t)mvpIdx;
+  }
+}
+
+/* neighbour motion (getPULeft / Above / AboveRight / BelowLeft / AboveLeft): inside the picture, in this slice, earlier in
+ * z-scan than the corner partition (cx, cy) the lookup starts from; data from the working CU when inside it */
+struct Nb { int avail, inter, skip, mvx, mvy, ref; };
+FCU_DEV Nb nb_motion(const Env E, const CuObj *cu, int nx, int ny, int cx, int cy)
+{
+  Nb r; r.avail = 0; r.inter = 0; r.skip = 0; r.mvx = 0; r.mvy = 0; r.ref = -1;
+  const Params &P = E.C->p;
+  if (nx < 0 || ny < 0 || nx >= P.width || ny >= P.height) return r;
+  const int ctuN = (ny >> 6) * E.C->w_ctu + (nx >> 6), ctuC = (cy >> 6) * E.C->w_ctu + (cx >> 6);
+  if (ctuN < E.slice_start || ctuN > ctuC) return r;
+  if (ctuN == ctuC && !(zidx_of(nx, ny) < zidx_of(cx, cy))) return r;
+  r.avail = 1;
+  if (inside_cu(cu, nx, ny)) {
+    const int p = zidx_of(nx, ny) - cu->zidx;
+    r.inter = cu->pred_mode[p] == MODE_INTER; r.skip = cu->skip[p]; r.mvx = cu->mv[p][0]; r.mvy = cu->mv[p][1]; r.ref = cu->ref_idx[p];
+  } else {
+    const fcu_ctu_out *c = &E.C->out[ctuN]; const int p = zidx_of(nx, ny);
+    r.inter = c->pred_mode[p] == MODE_INTER; r.skip = c->skip[p]; r.mvx = c->mv[p][0]; r.mvy = c->mv[p][1]; r.ref = c->ref_idx[p];
+  }
+  return r;
+}
+FCU_DEV int same_motion(const Nb &a, const Nb &b) { return a.mvx == b.mvx && a.mvy == b.mvy && a.ref == b.ref; }
+
+/* getInterMergeCandidates (P slice, no TMVP) -> g_S.mrg_mv / mrg_ref; one lane */
+FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  const int xP = cu->x + g.ox, yP = cu->y + g.oy, w = g.w, h = g.h, maxc = E.C->p.max_merge_cand;
+  const int lbx = xP, lby = yP + h - 1, rtx = xP + w - 1, rty = yP;
+  int n = 0;
+#define FCU_ADD_MRG(nb) do { g_S.mrg_mv[n][0] = (nb).mvx; g_S.mrg_mv[n][1] = (nb).mvy; g_S.mrg_ref[n] = (nb).ref; n++; } while (0)
+  const Nb a1 = nb_motion(E, cu, xP - 1, yP + h - 1, lbx, lby);
+  const int okA1 = a1.avail && !(pu == 1 && ps == SIZE_Nx2N) && a1.inter;
+  if (okA1) FCU_ADD_MRG(a1);
+  const Nb b1 = nb_motion(E, cu, xP + w - 1, yP - 1, rtx, rty);
+  const int okB1 = b1.avail && !(pu == 1 && ps == SIZE_2NxN) && b1.inter;
+  if (n < maxc && okB1 && (!okA1 || !same_motion(a1, b1))) FCU_ADD_MRG(b1);
+  const Nb b0 = nb_motion(E, cu, xP + w, yP - 1, rtx, rty);
+  const int okB0 = b0.avail && b0.inter;
+  if (n < maxc && okB0 && (!okB1 || !same_motion(b1, b0))) FCU_ADD_MRG(b0);
+  const Nb a0 = nb_motion(E, cu, xP - 1, yP + h, lbx, lby);
+  const int okA0 = a0.avail && a0.inter;
+  if (n < maxc && okA0 && (!okA1 || !same_motion(a1, a0))) FCU_ADD_MRG(a0);
+  if (n < maxc && n < 4) {
+    const Nb b2 = nb_motion(E, cu, xP - 1, yP - 1, xP, yP);
+    if (b2.avail && b2.inter && (!okA1 || !same_motion(a1, b2)) && (!okB1 || !same_motion(b1, b2))) FCU_ADD_MRG(b2);
+  }
+  while (n < maxc) { g_S.mrg_mv[n][0] = g_S.mrg_mv[n][1] = 0; g_S.mrg_ref[n] = 0; n++; }
+#undef FCU_ADD_MRG
+}
+/* fillMvpCand (one reference picture, no TMVP) -> g_S.amvp; one lane */
+FCU_DEV FCU_NOINLINE void amvp_candidates(const CuObj *cu, int ps, int pu)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  const int xP = cu->x + g.ox, yP = cu->y + g.oy, w = g.w, h = g.h;
+  const int lbx = xP, lby = yP + h - 1, rtx = xP + w - 1, rty = yP;
+  int n = 0;
+  const Nb a0 = nb_motion(E, cu, xP - 1, yP + h, lbx, lby), a1 = nb_motion(E, cu, xP - 1, yP + h - 1, lbx, lby);
+  const int addedSmvp = (a0.avail && a0.inter) || (a1.avail && a1.inter);
+  if (a0.avail && a0.ref >= 0) { g_S.amvp[n][0] = a0.mvx; g_S.amvp[n][1] = a0.mvy; n++; }
+  else if (a1.avail && a1.ref >= 0) { g_S.amvp[n][0] = a1.mvx; g_S.amvp[n][1] = a1.mvy; n++; }
+  const Nb b0 = nb_motion(E, cu, xP + w, yP - 1, rtx, rty), b1 = nb_motion(E, cu, xP + w - 1, yP - 1, rtx, rty), b2 = nb_motion(E, cu, xP - 1, yP - 1, xP, yP);
+  int ax = 0, ay = 0, haveAbove = 1;
+  if (b0.avail && b0.ref >= 0) { ax = b0.mvx; ay = b0.mvy; }
+  else if (b1.avail && b1.ref >= 0) { ax = b1.mvx; ay = b1.mvy; }
+  else if (b2.avail && b2.ref >= 0) { ax = b2.mvx; ay = b2.mvy; }
+  else haveAbove = 0;
+  if (haveAbove) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }
+  if (!addedSmvp && haveAbove && n < 2) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }        /* xAddMVPCandOrder repeats it */
+  if (n == 2 && g_S.amvp[0][0] == g_S.amvp[1][0] && g_S.amvp[0][1] == g_S.amvp[1][1]) n = 1;
+  while (n < 2) { g_S.amvp[n][0] = g_S.amvp[n][1] = 0; n++; }
+}
+FCU_DEV void clip_mv(const Params &P, const CuObj *cu, int &x, int &y)            /* clipMv, TComDataCU.cpp:2930-2942 */
+{
+  const int hmax = (P.width + 8 - cu->x - 1) << 2, hmin = (-64 - 8 - cu->x + 1) << 2;
+  const int vmax = (P.height + 8 - cu->y - 1) << 2, vmin = (-64 - 8 - cu->y + 1) << 2;
+  x = x > hmax ? hmax : (x < hmin ? hmin : x); y = y > vmax ? vmax : (y < vmin ? vmin : y);
+}
+
+/* ---- interpolation (TComInterpolationFilter as xPredInterBlk applies it): every path equals
+ * clip8((sum_v sum_h c_v c_h s + 2048) >> 12) with the {64} filter for a zero fraction; the reference planes are padded */
+FCU_TABLE int8_t k_luma_filter[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+FCU_TABLE int8_t k_chroma_filter[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+/* sample (x, y) of the component plane displaced by (mvx, mvy) (luma: quarter units, chroma: eighth units) */
+FCU_DEV int interp_sample(const uint8_t *ref, int rs, int comp, int x, int y, int mvx, int mvy)
+{
+  const int sh = comp ? 3 : 2, msk = (1 << sh) - 1, fx = mvx & msk, fy = mvy & msk;
+  const uint8_t *p = ref + (y + (mvy >> sh)) * rs + x + (mvx >> sh);
+  if (!fx && !fy) return p[0];
+  if (comp == 0) {
+    if (!fy) { int s = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * p[t - 3];
+      return clip8((s + 32) >> 6); }
+    if (!fx) { int s = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) s += k_luma_filter[fy][t] * p[(t - 3) * rs];
+      return clip8((s + 32) >> 6); }
+    int s = 0;
+    for (int j = 0; j < 8; j++) { int h = 0; const uint8_t *q = p + (j - 3) * rs;
+#pragma unroll
+      for (int t = 0; t < 8; t++) h += k_luma_filter[fx][t] * q[t - 3];
+      s += k_luma_filter[fy][j] * h; }
+    return clip8((s + 2048) >> 12);
+  }
+  int s = 0;
+  for (int j = 0; j < 4; j++) { int h = 0; const uint8_t *q = p + (j - 1) * rs;
+#pragma unroll
+    for (int t = 0; t < 4; t++) h += k_chroma_filter[fx][t] * q[t - 1];
+    s += k_chroma_filter[fy][j] * h; }
+  return clip8((s + 2048) >> 12);
+}
+/* block of the component plane at (bx, by), size w x h, displaced by mv -> dst (all lanes; caller supplies the phase) */
+FCU_DEV void mc_block_lanes(const Env E, int lane, int comp, int bx, int by, int w, int h, int mvx, int mvy, uint8_t *dst, int ds)
+{
+  const uint8_t *ref = E.C->ref[comp]; const int rs = E.C->ref_stride[comp];
+  for (int i = lane; i < w * h; i += 64) { const int y = i / w, x = i - y * w; dst[y * ds + x] = (uint8_t)interp_sample(ref, rs, comp, bx + x, by + y, mvx, mvy); }
+}
+/* motionCompensation of one PU into a CU-sized buffer (the vector is clipped first, xPredInterUni) */
+FCU_DEV FCU_NOINLINE void mc_pu(const CuObj *cu, int ps, int pu, Yuv *dst, int lumaOnly)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); dst = FCU_UNI(dst); lumaOnly = FCU_UNI(lumaOnly);
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  int mvx = FCU_UNI((int)cu->mv[g.addr][0]), mvy = FCU_UNI((int)cu->mv[g.addr][1]);
+  clip_mv(E.C->p, cu, mvx, mvy);
+  FCU_FOR_LANES {
+    mc_block_lanes(E, lane, 0, cu->x + g.ox, cu->y + g.oy, g.w, g.h, mvx, mvy, dst->y + g.oy * 64 + g.ox, 64);
+    if (!lumaOnly) {
+      mc_block_lanes(E, lane, 1, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->u + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
+      mc_block_lanes(E, lane, 2, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->v + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
+    }
+  }
+}
+
+/* ---- motion-vector cost: unsigned 32-bit arithmetic as in the reference */
+FCU_DEV uint32_t mv_comp_bits(int v) { uint32_t len = 1, t = (v <= 0) ? (((uint32_t)(-v)) << 1) + 1 : ((uint32_t)v << 1); while (t != 1) { t >>= 1; len += 2; } return len; }
+FCU_DEV uint32_t mv_bits(int x, int y, int px, int py, int scale) { return mv_comp_bits((x << scale) - px) + mv_comp_bits((y << scale) - py); }
+FCU_DEV uint32_t motion_cost(const Params &P, uint32_t bits) { return (P.lambda_motion_sad * bits) >> 16; }
+
+#ifdef FCU_EMU
+static inline uint32_t fcu_sad_u8(uint32_t a, uint32_t b, uint32_t acc)
+{ for (int k = 0; k < 4; k++) { const int d = (int)((a >> (8 * k)) & 255) - (int)((b >> (8 * k)) & 255); acc += (uint32_t)(d < 0 ? -d : d); } return acc; }
+#else
+__device__ inline uint32_t fcu_sad_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+#endif
+/* SAD of the w x h source block (stride 64, in the chain's scratch) against the reference at `r`, rows 0, step, 2*step.. */
+FCU_DEV uint32_t sad_block(const uint8_t *org, const uint8_t *r, int rs, int w, int h, int step)
+{
+  uint32_t s = 0;
+  for (int y = 0; y < h; y += step) {
+    const uint8_t *o = org + y * 64, *q = r + y * rs;
+    for (int x = 0; x < w; x += 4) { uint32_t a, b; __builtin_memcpy(&a, o + x, 4); __builtin_memcpy(&b, q + x, 4); s = fcu_sad_u8(a, b, s); }
+  }
+  return s;
+}
+/* Hadamard SATD of one USZ x USZ block from two sample buffers (xCalcHADs8x8 / 4x4), same scheme as satd_unit */
+template <int USZ>
+FCU_DEV uint32_t had_unit(const uint8_t *org, int so, const uint8_t *pred, int sp)
+{
+  int acc[USZ * USZ];
+#pragma unroll
+  for (int i = 0; i < USZ * USZ; i++) acc[i] = 0;
+  for (int y = 0; y < USZ; y++) {
+    int row[USZ];
+#pragma unroll
+    for (int x = 0; x < USZ; x++) row[x] = (int)org[y * so + x] - (int)pred[y * sp + x];
+#pragma unroll
+    for (int len = 1; len < USZ; len <<= 1)
+#pragma unroll
+      for (int i = 0; i < USZ; i += 2 * len)
+#pragma unroll
+        for (int j = i; j < i + len; j++) { const int a = row[j], b = row[j + len]; row[j] = a + b; row[j + len] = a - b; }
+#pragma unroll
+    for (int k = 0; k < USZ; k++) {
+      const int neg = -(__builtin_popcount((unsigned)(k & y)) & 1);
+#pragma unroll
+      for (int j = 0; j < USZ; j++) acc[k * USZ + j] += (row[j] ^ neg) - neg;
+    }
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < USZ * USZ; i++) s += iabs(acc[i]);
+  return (uint32_t)(USZ == 8 ? ((s + 2) >> 2) : ((s + 1) >> 1));
+}
+/* xGetHADs of a w x h block: 8x8 units when both dimensions allow, else 4x4; lanes share the units, the sum lands in *accp */
+FCU_DEV void had_block_lanes(int lane, const uint8_t *org, int so, const uint8_t *pred, int sp, int w, int h, uint32_t *accp)
+{
+  uint32_t part = 0;
+  if (!(w & 7) && !(h & 7)) { const int bw = w >> 3, nb = bw * (h >> 3); for (int u = lane; u < nb; u += 64) part += had_unit<8>(org + (u / bw) * 8 * so + (u % bw) * 8, so, pred + (u / bw) * 8 * sp + (u % bw) * 8, sp); }
+  else { const int bw = w >> 2, nb = bw * (h >> 2); for (int u = lane; u < nb; u += 64) part += had_unit<4>(org + (u / bw) * 4 * so + (u % bw) * 4, so, pred + (u / bw) * 4 * sp + (u % bw) * 4, sp); }
+  FCU_WAVE_ADD(accp, part);
+}
+
+/* xGetInterPredictionError: MC of the PU (luma) + Hadamard against the source -> return value (uniform) */
+FCU_DEV FCU_NOINLINE uint32_t inter_pred_error(const CuObj *cu, int ps, int pu)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  mc_pu(cu, ps, pu, &E.G->tmp_pred, 1);
+  FCU_SERIAL g_S.acc[0] = 0;
+  const uint8_t *org = E.G->org[cu->depth_cu].y + g.oy * 64 + g.ox, *p = E.G->tmp_pred.y + g.oy * 64 + g.ox;
+  FCU_FOR_LANES {
+    if (E.C->p.had_me) had_block_lanes(lane, org, 64, p, 64, g.w, g.h, &g_S.acc[0]);
+    else { uint32_t s = 0; for (int i = lane; i < g.w * g.h; i += 64) s += (uint32_t)iabs(org[(i / g.w) * 64 + i % g.w] - p[(i / g.w) * 64 + i % g.w]); FCU_WAVE_ADD(&g_S.acc[0], s); }
+  }
+  return FCU_UNI(g_S.acc[0]);
+}
+
+/* ---- xEstimateMvPredAMVP + xGetTemplateCost: best of the two candidates -> returns its index (uniform) */
+FCU_DEV FCU_NOINLINE int estimate_mvp(const CuObj *cu, int ps, int pu)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  const Params &P = E.C->p;
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  FCU_SERIAL { amvp_candidates(cu, ps, pu); g_S.acc[0] = g_S.acc[1] = 0; }
+  const uint8_t *org = E.G->org[cu->depth_cu].y + g.oy * 64 + g.ox;
+  for (int i = 0; i < 2; i++) {
+    int cx = FCU_UNI(g_S.amvp[i][0]), cy = FCU_UNI(g_S.amvp[i][1]);
+    clip_mv(P, cu, cx, cy);
+    FCU_FOR_LANES {
+      uint32_t s = 0;
+      for (int k = lane; k < g.w * g.h; k += 64) { const int y = k / g.w, x = k - y * g.w; s += (uint32_t)iabs(org[y * 64 + x] - interp_sample(E.C->ref[0], E.C->ref_stride[0], 0, cu->x + g.ox + x, cu->y + g.oy + y, cx, cy)); }
+      FCU_WAVE_ADD(&g_S.acc[i], s);
+    }
+  }
+  /* calcRdCost(bits = 1, SAD, false, DF_SAD): floor(SAD + floor(lambdaMotionSAD + 0.5) / 65536) */
+  const double add = FCU_FLOOR((double)P.lambda_motion_sad + 0.5) / 65536.0;
+  const uint32_t c0 = (uint32_t)FCU_FLOOR((double)FCU_UNI(g_S.acc[0]) + add), c1 = (uint32_t)FCU_FLOOR((double)FCU_UNI(g_S.acc[1]) + add);
+  return c1 < c0 ? 1 : 0;
+}
+
+/* ---- xMotionEstimation: full search (xPatternSearch) + xPatternSearchFracDIF.  Results in g_S.me_out: [0] mvx, [1] mvy,
+ * g_S.acc[12] bits, g_S.acc[13] cost. */
+FCU_TABLE int8_t k_refine_h[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+FCU_TABLE int8_t k_refine_q[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
+FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int predx, int predy, uint32_t bitsIn)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); predx = FCU_UNI(predx); predy = FCU_UNI(predy); bitsIn = FCU_UNI(bitsIn);
+  const Params &P = E.C->p; Scratch *G = E.G;
+  const Pu g = pu_geom(cu->depth_cu, ps, pu);
+  const uint8_t *org = G->org[cu->depth_cu].y + g.oy * 64 + g.ox;
+  const int px = cu->x + g.ox, py = cu->y + g.oy, rng = P.search_range, rs = E.C->ref_stride[0];
+  const uint8_t *ref0 = E.C->ref[0];
+  /* xSetSearchRange */
+  int cx = predx, cy = predy; clip_mv(P, cu, cx, cy);
+  int ltx = cx - (rng << 2), lty = cy - (rng << 2), rbx = cx + (rng << 2), rby = cy + (rng << 2);
+  clip_mv(P, cu, ltx, lty); clip_mv(P, cu, rbx, rby);
+  ltx >>= 2; lty >>= 2; rbx >>= 2; rby >>= 2;
+  const int nx = rbx - ltx + 1, ny = rby - lty + 1, step = (P.fast_enc && g.h > 8) ? 2 : 1;
+  FCU_SERIAL g_S.me_best = ~0ull;
+  FCU_FOR_LANES {                                            /* one candidate position per lane */
+    unsigned long long best = ~0ull;
+    for (int p = lane; p < nx * ny; p += 64) {
+      const int yy = p / nx, xx = p - yy * nx, x = ltx + xx, y = lty + yy;
+      uint32_t s = sad_block(org, ref0 + (py + y) * rs + px + x, rs, g.w, g.h, step);
+      if (step == 2) s <<= 1;
+      s += motion_cost(P, mv_bits(x, y, predx, predy, 2));
+      const unsigned long long key = ((unsigned long long)s << 32) | (unsigned)p;     /* ties: the earlier raster position wins */
+      if (key < best) best = key;
+    }
+    FCU_WAVE_MIN64(&g_S.me_best, best);
+  }
+  const unsigned bp = (unsigned)FCU_UNI((int)(unsigned)(g_S.me_best & 0xffffffffull));
+  const int bx = ltx + (int)(bp % (unsigned)nx), by = lty + (int)(bp / (unsigned)nx);
+  /* half-sample round, then quarter-sample round around the winner */
+  int hx = 0, hy = 0, qx = 0, qy = 0; uint32_t bestD = 0;
+  for (int round = 0; round < 2; round++) {
+    const int basex = (bx << 2) + 2 * hx, basey = (by << 2) + 2 * hy, stp = round == 0 ? 2 : 1;
+    FCU_FOR_LANES {                                          /* the nine interpolated blocks */
+      if (lane < 9) g_S.acc[lane] = 0;
+      for (int k = lane; k < 9 * g.w * g.h; k += 64) {
+        const int c = k / (g.w * g.h), r = k - c * g.w * g.h, y = r / g.w, x = r - y * g.w;
+        const int8_t *t = round == 0 ? k_refine_h[c] : k_refine_q[c];
+        G->me_pred[c][y * 64 + x] = (uint8_t)interp_sample(ref0, rs, 0, px + x, py + y, basex + stp * t[0], basey + stp * t[1]);
+      }
+    }
+    for (int c = 0; c < 9; c++) {
+      FCU_FOR_LANES {
+        if (P.had_me) had_block_lanes(lane, org, 64, G->me_pred[c], 64, g.w, g.h, &g_S.acc[c]);
+        else { uint32_t s = 0; for (int i = lane; i < g.w * g.h; i += 64) s += (uint32_t)iabs(org[(i / g.w) * 64 + i % g.w] - G->me_pred[c][(i / g.w) * 64 + i % g.w]); FCU_WAVE_ADD(&g_S.acc[c], s); }
+      }
+    }
+    uint32_t best = 0xffffffffu; int bi = 0;
+    for (int c = 0; c < 9; c++) {
+      const int8_t *t = round == 0 ? k_refine_h[c] : k_refine_q[c];
+      uint32_t d = FCU_UNI(g_S.acc[c]);
+      if (round == 0) d += motion_cost(P, mv_bits((bx << 1) + t[0], (by << 1) + t[1], predx, predy, 1));
+      else d += motion_cost(P, mv_bits(basex + t[0], basey + t[1], predx, predy, 0));
+      if (d < best) { best = d; bi = c; }
+    }
+    if (round == 0) { hx = k_refine_h[bi][0]; hy = k_refine_h[bi][1]; }
+    else { qx = k_refine_q[bi][0]; qy = k_refine_q[bi][1]; bestD = best; }
+  }
+  const int mvx = (bx << 2) + 2 * hx + qx, mvy = (by << 2) + 2 * hy + qy;
+  const uint32_t mvBits = mv_bits(mvx, mvy, predx, predy, 0), bits = bitsIn + mvBits;
+  const uint32_t cost = (uint32_t)(FCU_FLOOR(1.0 * ((double)bestD - (double)motion_cost(P, mvBits))) + (double)motion_cost(P, bits));
+  FCU_SERIAL { g_S.me_out[0] = mvx; g_S.me_out[1] = mvy; g_S.acc[12] = bits; g_S.acc[13] = cost; }
+}
+
+/* ---- predInterSearch (P slice, one reference picture): motion of every PU of the CU + its prediction in predt[d] */
+FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps);
+  const Params &P = E.C->p; Scratch *G = E.G;
+  const int d = cu->depth_cu, npu = pu_count(ps);
+  for (int pu = 0; pu < npu; pu++) {
+    const uint32_t mbBits = (ps == SIZE_2Nx2N || ps == SIZE_NxN) ? 1 : 3;      /* xGetBlkBits, P slice */
+    int mvpIdx = estimate_mvp(cu, ps, pu);
+    int predx = FCU_UNI(g_S.amvp[mvpIdx][0]), predy = FCU_UNI(g_S.amvp[mvpIdx][1]);
+    motion_estimation(cu, ps, pu, predx, predy, mbBits + 1);
+    const int mvx = FCU_UNI(g_S.me_out[0]), mvy = FCU_UNI(g_S.me_out[1]);
+    uint32_t bitsT = FCU_UNI(g_S.acc[12]), costT = FCU_UNI(g_S.acc[13]);
+    {                                                        /* xCheckBestMVP */
+      const int orgBits = (int)mv_bits(mvx, mvy, predx, predy, 0) + 1;
+      int bestBits = orgBits, bestIdx = mvpIdx;
+      for (int i = 0; i < 2; i++) {
+        if (i == mvpIdx) continue;
+        const int b = (int)mv_bits(mvx, mvy, FCU_UNI(g_S.amvp[i][0]), FCU_UNI(g_S.amvp[i][1]), 0) + 1;
+        if (b < bestBits) { bestBits = b; bestIdx = i; }
+      }
+      if (bestIdx != mvpIdx) {
+        predx = FCU_UNI(g_S.amvp[bestIdx][0]); predy = FCU_UNI(g_S.amvp[bestIdx][1]); mvpIdx = bestIdx;
+        const uint32_t org = bitsT;
+        bitsT = org - (uint32_t)orgBits + (uint32_t)bestBits;
+        costT = (costT - motion_cost(P, org)) + motion_cost(P, bitsT);
+      }
+    }
+    FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); pu_set_info(cu, ps, pu, lane, 0, 0, mvx - predx, mvy - predy, mvpIdx); }
+    if (ps != SIZE_2Nx2N) {                                  /* merge estimation of the PU (TEncSearch.cpp:3448-3498) */
+      const uint32_t meCost = inter_pred_error(cu, ps, pu) + motion_cost(P, bitsT);
+      FCU_SERIAL merge_candidates(cu, ps, pu);
+      uint32_t mrgCost = 0xffffffffu; int mrgIdx = 0;
+      const int nc = P.max_merge_cand;
+      for (int c = 0; c < nc; c++) {                          /* xMergeEstimation */
+        const int cx = FCU_UNI(g_S.mrg_mv[c][0]), cy = FCU_UNI(g_S.mrg_mv[c][1]), cr = FCU_UNI(g_S.mrg_ref[c]);
+        FCU_FOR_LANES pu_set_motion(cu, ps, pu, lane, cx, cy, cr);
+        uint32_t cc = inter_pred_error(cu, ps, pu);
+        uint32_t b = (uint32_t)c + 1; if (c == nc - 1) b--;
+        cc += motion_cost(P, b);
+        if (cc < mrgCost) { mrgCost = cc; mrgIdx = c; }
+      }
+      if (mrgCost < meCost) {
+        const int cx = FCU_UNI(g_S.mrg_mv[mrgIdx][0]), cy = FCU_UNI(g_S.mrg_mv[mrgIdx][1]), cr = FCU_UNI(g_S.mrg_ref[mrgIdx]);
+        FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, cx, cy, cr); pu_set_info(cu, ps, pu, lane, 1, mrgIdx, 0, 0, -1); }
+      } else {
+        FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); const int n = cu->nparts; for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) { cu->merge_flag[i] = 0; cu->merge_idx[i] = 0; cu->inter_dir[i] = 1; } }
+      }
+    }
+    mc_pu(cu, ps, pu, &G->predt[d], 0);
+  }
+}
+
+/* ---- inter syntax (one lane, coder id c) ------------------------------------------------ */
+FCU_DEV void code_skip_flag(const Env E, int c, const CuObj *cu, int part)                   /* TEncSbac.cpp:540-555 */
+{
+  const int z = cu->zidx + part, lx = (cu->x & ~63) + part_x(z), ly = (cu->y & ~63) + part_y(z);
+  const Nb l = nb_motion(E, cu, lx - 1, ly, lx, ly), a = nb_motion(E, cu, lx, ly - 1, lx, ly);
+  cab_bin(c, cu->skip[part], CTX_SKIP + (l.avail ? l.skip : 0) + (a.avail ? a.skip : 0));
+}
+FCU_DEV void code_pred_mode(int c, const CuObj *cu, int part) { cab_bin(c, cu->pred_mode[part] == MODE_INTRA, CTX_PRED_MODE); }
+FCU_DEV void code_merge_index(const Env E, int c, const CuObj *cu, int part)
+{
+  const int idx = cu->merge_idx[part], n = E.C->p.max_merge_cand;
+  for (int ui = 0; ui < n - 1; ui++) { const int sym = ui == idx ? 0 : 1; if (ui == 0) cab_bin(c, sym, CTX_MERGE_IDX); else cab_ep(c, 1); if (!sym) break; }
+}
+FCU_DEV void code_part_size_inter(int c, const CuObj *cu, int part, int depth)              /* TEncSbac.cpp:436-520, AMP off */
+{
+  const int ps = cu->part_size[part];
+  if (ps == SIZE_2Nx2N) { cab_bin(c, 1, CTX_PARTSIZE); return; }
+  cab_bin(c, 0, CTX_PARTSIZE);
+  if (ps == SIZE_2NxN) { cab_bin(c, 1, CTX_PARTSIZE1); return; }
+  cab_bin(c, 0, CTX_PARTSIZE1);
+  if (depth == MAXDEPTH && !((CTU >> depth) == 8)) cab_bin(c, 1, CTX_PARTSIZE1 + 1);
+}
+FCU_DEV int ep_exgolomb_bins(uint32_t symbol, uint32_t count) { int n = 0; while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; } return n + 1 + (int)count; }
+FCU_DEV void code_mvd(int c, int hor, int ver)                                             /* TEncSbac.cpp:780-830 */
+{
+  cab_bin(c, hor != 0, CTX_MVD); cab_bin(c, ver != 0, CTX_MVD);
+  const uint32_t ah = (uint32_t)iabs(hor), av = (uint32_t)iabs(ver);
+  if (hor) cab_bin(c, ah > 1, CTX_MVD + 1);
+  if (ver) cab_bin(c, av > 1, CTX_MVD + 1);
+  if (hor) { if (ah > 1) cab_ep(c, ep_exgolomb_bins(ah - 2, 1)); cab_ep(c, 1); }
+  if (ver) { if (av > 1) cab_ep(c, ep_exgolomb_bins(av - 2, 1)); cab_ep(c, 1); }
+}
+FCU_DEV void code_pu_wise(const Env E, int c, const CuObj *cu, int part)                    /* TEncEntropy.cpp:456-507 */
+{
+  const int ps = cu->part_size[part], npu = pu_count(ps), n = NPART >> (2 * cu->depth[part]);
+  const int off = ps == SIZE_2NxN ? n >> 1 : (ps == SIZE_2Nx2N ? 0 : n >> 2);
+  for (int pu = 0, sp = part; pu < npu; pu++, sp += off) {
+    cab_bin(c, cu->merge_flag[sp], CTX_MERGE_FLAG);
+    if (cu->merge_flag[sp]) code_merge_index(E, c, cu, sp);
+    else { code_mvd(c, cu->mvd[sp][0], cu->mvd[sp][1]); cab_bin(c, cu->mvp_idx[sp], CTX_MVP_IDX); }
+  }
+}
+FCU_DEV int qt_root_cbf(const CuObj *cu, int part) { return (cu->cbf[0][part] | cu->cbf[1][part] | cu->cbf[2][part]) & 1; }
+FCU_DEV int min_tu_log2_inter(int depth) { int l = 6 - depth; if (l < LOG2_MINTU + 2) return LOG2_MINTU; l -= 2; return l > LOG2_MAXTU ? LOG2_MAXTU : l; }   /* QuadtreeTUMaxDepthInter 3 */
+FCU_DEV int qt_cbf_ctx(const TU &tu, int comp) { return comp ? CTX_CBF_CHROMA + tu.tr_depth : CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0); }
+
+/* final-order transform tree of an inter CU (xEncodeTransform, inter branch): iterative, one lane */
+FCU_DEV FCU_NOINLINE void encode_transform_inter(int c, const CuObj *cu, int cuPart, uint32_t root_k)
+{
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); cuPart = FCU_UNI(cuPart); const TU root = tu_of_key(FCU_UNI(root_k));
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU tu = st[sp];
+    if (ci[sp] < 0) {
+      const int part = cuPart + tu.part, trIdx = tu.tr_depth, subdiv = cu->tr_idx[part] > trIdx;
+      if (tu.log2 > LOG2_MAXTU) { }
+      else if (tu.log2 == LOG2_MINTU) { }
+      else if (tu.log2 == min_tu_log2_inter(cu->depth[part])) { }
+      else cab_bin(c, subdiv, CTX_SUBDIV + 5 - tu.log2);
+      const int first = trIdx == 0;
+      for (int comp = 1; comp < 3; comp++)
+        if (first || tu.c_code_all)
+          if (first || ((cu->cbf[comp][part] >> (trIdx - 1)) & 1)) {
+            const int lowest = trIdx + ((subdiv && !(tu.cwo >= 8)) ? 1 : 0);
+            cab_bin(c, (cu->cbf[comp][cuPart + tu_part_c(tu)] >> lowest) & 1, CTX_CBF_CHROMA + trIdx);
+          }
+      if (!subdiv) {
+        if (!(trIdx == 0 && !((cu->cbf[1][part] & 1) || (cu->cbf[2][part] & 1)))) cab_bin(c, (cu->cbf[0][part] >> trIdx) & 1, CTX_CBF_LUMA + (trIdx == 0 ? 1 : 0));
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && tu.cw == 0) continue;
+          if (!((cu->cbf[comp][part] >> trIdx) & 1)) continue;
+          const int log2 = comp ? ilog2(tu.cw) : tu.log2, pc = cuPart + (comp ? tu_part_c(tu) : tu.part);
+          const int16_t *coef = cu->coef[comp] + (comp ? (cuPart * 4 + tu.off_c) : (cuPart * 16 + tu.off_y));
+          code_coeff_nxn<1>(c, coef, 1, -1, log2, comp, 0, cu->tskip[comp][pc], E.C->p, g_S.lane_abs[0]);
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 1); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+FCU_DEV void encode_cu_syntax_inter(const Env E, int c, const CuObj *cu, int cuPart, int depth)   /* xAddSymbolBitsInter / xEncodeCU */
+{
+  code_skip_flag(E, c, cu, cuPart);
+  if (cu->skip[cuPart]) { code_merge_index(E, c, cu, cuPart); return; }
+  code_pred_mode(c, cu, cuPart);
+  code_part_size_inter(c, cu, cuPart, depth);
+  code_pu_wise(E, c, cu, cuPart);
+  if (!(cu->merge_flag[cuPart] && cu->part_size[cuPart] == SIZE_2Nx2N)) cab_bin(c, qt_root_cbf(cu, cuPart), CTX_ROOT_CBF);
+  if (!qt_root_cbf(cu, cuPart)) return;
+  TU root; tu_root(root, depth);
+  encode_transform_inter(c, cu, cuPart, tu_key(root));
+}
+
+/* xEncodeInterResidualQT on the search-time buffers: pass 3 = subdivision / cbf flags, pass 0..2 = coefficients of a
+ * component; iterative, one lane */
+FCU_DEV FCU_NOINLINE void encode_inter_residual_qt(int c, const CuObj *cu, uint32_t root_k, int pass)
+{
+  const Env E = env_get(); c = FCU_UNI(c); cu = FCU_UNI(cu); const TU root = tu_of_key(FCU_UNI(root_k)); pass = FCU_UNI(pass);
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
+  st[0] = root; ci[0] = -1;
+  while (sp >= 0) {
+    const TU tu = st[sp];
+    if (ci[sp] < 0) {
+      const int cur = tu.tr_depth, trMode = cu->tr_idx[tu.part], subdiv = cur != trMode, log2 = tu.log2;
+      if (pass == 3) {
+        if (log2 <= LOG2_MAXTU && log2 > min_tu_log2_inter(cu->depth_cu)) cab_bin(c, subdiv, CTX_SUBDIV + 5 - log2);
+        const int first = cur == 0;
+        for (int comp = 1; comp < 3; comp++)
+          if (first || tu.c_code_all)
+            if (first || ((cu->cbf[comp][tu.part] >> (cur - 1)) & 1)) {
+              const int lowest = cur + ((subdiv && !(tu.cw >= 8)) ? 1 : 0);
+              cab_bin(c, (cu->cbf[comp][tu_part_c(tu)] >> lowest) & 1, CTX_CBF_CHROMA + cur);
+            }
+        if (!subdiv) cab_bin(c, (cu->cbf[0][tu.part] >> cur) & 1, CTX_CBF_LUMA + (cur == 0 ? 1 : 0));
+      }
+      if (!subdiv) {
+        if (pass != 3 && !(pass && tu.cw == 0) && ((cu->cbf[pass][tu.part] >> trMode) & 1)) {
+          const int layer = LOG2_MAXTU - log2, l2 = pass ? ilog2(tu.cw) : log2;
+          code_coeff_nxn<1>(c, E.G->qt_coef[pass][layer] + (pass ? tu.off_c : tu.off_y), 1, -1, l2, pass, 0, cu->tskip[pass][pass ? tu_part_c(tu) : tu.part], E.C->p, g_S.lane_abs[0]);
+        }
+        sp--; continue;
+      }
+      if (!(pass == 3 || ((cu->cbf[pass][tu.part] >> cur) & 1))) { sp--; continue; }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+
+/* ---- one transform unit coded whole: the bCheckFull part of xEstimateInterResidualQT.  Its Y / Cb / Cr (x transform-skip)
+ * variants all restart from the snapshot in the go-on coder, so transform, RDOQ, reconstruction and bit count of all of
+ * them run side by side.  Leaves the chosen levels / residual in the RQT layer buffers, the flags in the CU, the coder
+ * after the TU's syntax in the go-on coder and (single bits, single distortion) in g_S.iv_bits[0] / g_S.iv_dist[0]. */
+FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); addZero = FCU_UNI(addZero);
+  Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, trMode = tu.tr_depth, depth = d + trMode, log2 = tu.log2, layer = LOG2_MAXTU - log2, part = tu.part;
+  const int NY = 1 << log2, NC = tu.cw, lc = NC ? ilog2(NC) : 0, ncomp = NC ? 3 : 1;
+  const int tsY = P.transform_skip && NY == 4, tsC = P.transform_skip && NC == 4;
+  /* variant table (uniform): v = 2 * comp + ts; block b = comp at p_resi[boff[b]] */
+  const int bN[3] = { NY, NC, NC }, bl2[3] = { log2, lc, lc }, boff[3] = { 0, NY * NY, NY * NY + NC * NC };
+  const int btot = NY * NY + (NC ? 2 * NC * NC : 0);
+  auto voff = [&](int v) { return (v & 1) ? 1536 + boff[v >> 1] : boff[v >> 1]; };        /* transform-skip variants (4x4 only) live behind the coded ones */
+  auto vok = [&](int v) { const int comp = v >> 1; return comp < ncomp && (!(v & 1) || (comp ? tsC : tsY)); };
+  FCU_FOR_LANES {                                            /* residual blocks + first transform stage */
+    for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)trMode;
+    if (lane < 6) { g_S.iv_top[lane] = -1; g_S.acc[lane] = 0; g_S.acc[6 + (lane >> 1)] = 0; }
+    for (int i = lane; i < btot; i += 64) {
+      const int b = i < boff[1] ? 0 : (i < boff[2] ? 1 : 2), k = i - boff[b], N = bN[b], y = k / N, x = k - y * N;
+      const int16_t *r = (b == 0 ? G->resi_cu.y + tu.y * 64 + tu.x : (b == 1 ? G->resi_cu.u : G->resi_cu.v) + tu.cy * 32 + tu.cx);
+      G->p_resi[i] = r[y * (b ? 32 : 64) + x];
+    }
+  }
+  FCU_FOR_LANES {
+    uint32_t z[3] = { 0, 0, 0 };
+    for (int i = lane; i < btot; i += 64) {
+      const int b = i < boff[1] ? 0 : (i < boff[2] ? 1 : 2), k = i - boff[b];
+      const int r = G->p_resi[i]; z[b] += (uint32_t)(r * r);
+      by_log2(bl2[b], [&](auto L) { G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + boff[b], 0, k); });
+    }
+    for (int b = 0; b < 3; b++) FCU_WAVE_ADD(&g_S.acc[6 + b], z[b]);
+  }
+  FCU_FOR_LANES {                                            /* second stage -> level_double in scan order (SCAN_DIAG) */
+    est_build(CAB_GOON, lane);
+    for (int v = 0; v < 6; v++) {
+      if (!vok(v)) continue;
+      const int comp = v >> 1, N = bN[comp], l2 = bl2[comp], n2 = N * N, o = voff(v);
+      const int qp = comp ? P.qp_c : P.qp, qbits = rdoq_qbits(l2, qp), qscale = k_quant_scales[qp % 6];
+      const uint16_t *iscan = k_iscan + k_scan_off[0 * 4 + l2 - 2];
+      for (int k = lane; k < n2; k += 64) {
+        int32_t t;
+        if (v & 1) t = (int32_t)G->p_resi[boff[comp] + k] << (15 - 8 - l2);
+        else by_log2(l2, [&](auto L) { t = fwd2<decltype(L)::value>(G->p_tmp + boff[comp], 0, k); });
+        const int sp = iscan[k]; const int32_t ld = level_double(t, qscale, qbits);
+        G->p_lscan[o + sp] = ld;
+        if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.iv_top[v], sp);
+      }
+    }
+  }
+  FCU_FOR_LANES {                                            /* RDOQ: one variant per lane, all priced against the snapshot */
+    if (lane < 6 && vok(lane)) {
+      const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane);
+      const int cbfCtx = (comp == 0 && trMode == 0) ? EST_ROOT_CBF : qt_cbf_ctx(tu, comp);      /* blockRootCbpBits, TComTrQuant.cpp:2358 */
+      const RdoqOut r = rdoq<0, 1>(CAB_GOON, G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp, 0, cbfCtx, P, G->r_rec + o, G->r_cg + lane * 64);
+      g_S.iv_abs[lane] = r.abs_sum; g_S.iv_lsp[lane] = r.last;
+    }
+    if (lane == 0) E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0));
+  }
+  FCU_FOR_LANES {                                            /* dequantisation (transposed for the inverse stages) */
+    for (int v = 0; v < 6; v++) {
+      if (!vok(v) || g_S.iv_abs[v] <= 0) continue;
+      const int comp = v >> 1, N = bN[comp], l2 = bl2[comp], n2 = N * N, o = voff(v);
+      const DeqParams dq = deq_params(l2, comp ? P.qp_c : P.qp);
+      const uint16_t *iscan = k_iscan + k_scan_off[0 * 4 + l2 - 2];
+      const int cgEnd = ((g_S.iv_top[v] >> 4) + 1) << 4;
+      for (int k = lane; k < n2; k += 64) { const int sp = iscan[k]; const int q = sp < cgEnd ? G->p_qscan[o + sp] : 0; G->p_tmp[2048 + o + ((v & 1) ? k : tr_index(k, l2))] = dequant1(q, dq); }
+    }
+  }
+  FCU_FOR_LANES {
+    for (int v = 0; v < 6; v++) {
+      if (!vok(v) || g_S.iv_abs[v] <= 0 || (v & 1)) continue;
+      const int comp = v >> 1, l2 = bl2[comp], n2 = bN[comp] * bN[comp], o = voff(v);
+      by_log2(l2, [&](auto L) { for (int k = lane; k < n2; k += 64) G->p_tcoef[o + k] = inv1<decltype(L)::value>(G->p_tmp + 2048 + o, 0, k); });
+    }
+  }
+  FCU_FOR_LANES {                                            /* reconstructed residual of every variant + its SSE against the residual */
+    for (int v = 0; v < 6; v++) {
+      if (!vok(v)) continue;
+      const int comp = v >> 1, l2 = bl2[comp], n2 = bN[comp] * bN[comp], o = voff(v);
+      uint32_t sse = 0;
+      if (g_S.iv_abs[v] > 0) {
+        for (int k = lane; k < n2; k += 64) {
+          int rr;
+          if (v & 1) { const int s = 15 - 8 - l2; rr = (int16_t)((G->p_tmp[2048 + o + k] + (1 << (s - 1))) >> s); }
+          else by_log2(l2, [&](auto L) { rr = (int16_t)inv2<decltype(L)::value>(G->p_tcoef + o, 0, k); });
+          G->p_resi[2048 + o + k] = (int16_t)rr;
+          const int e = rr - G->p_resi[boff[comp] + k]; sse += (uint32_t)(e * e);
+        }
+      }
+      FCU_WAVE_ADD(&g_S.acc[v], sse);
+    }
+  }
+  FCU_FOR_LANES {                                            /* bits of (cbf, coefficients) per variant on lane-private coders */
+    if (lane < 6 && vok(lane) && g_S.iv_abs[lane] > 0) {
+      const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane), c = CAB_LANE0 + lane;
+      cab_copy1(&g_S.cab[c], &g_S.cab[CAB_GOON]); cab_reset_bits(c);
+      cab_bin(c, 1, qt_cbf_ctx(tu, comp));
+      code_coeff_nxn<0>(c, G->p_qscan + o, 1, g_S.iv_lsp[lane], l2, comp, 0, lane & 1, P, g_S.lane_abs[lane]);
+      g_S.iv_bits[lane] = cab_bits(c);
+    }
+  }
+  FCU_SERIAL {                                               /* per component: coded / skipped / transform-skip (TEncSearch.cpp:4640-4900) */
+    const uint64_t low = g_S.cab[CAB_GOON].frac & 32767;
+    for (int comp = 0; comp < ncomp; comp++) {
+      const uint32_t sseZ = g_S.acc[6 + comp];
+      const uint32_t nonDist = comp ? (uint32_t)(P.chroma_weight * (double)sseZ) : sseZ;
+      const uint32_t nonBits = (uint32_t)((low + (uint64_t)ctx_bits(CAB_GOON, qt_cbf_ctx(tu, comp), 0)) >> 15);
+      const double nonCost = rd_cost(P, nonBits, nonDist);
+      if (addZero) g_S.iq_zero += nonDist;
+      double minCost = FCU_MAX_DOUBLE; int bAbs = 0, bTs = 0; uint32_t bDist = 0;
+      const int nModes = (comp ? tsC : tsY) ? 2 : 1;
+      for (int ts = 0; ts < nModes; ts++) {
+        const int v = 2 * comp + ts; int curAbs = g_S.iv_abs[v];
+        uint32_t curDist; double curCost;
+        if (curAbs > 0) { const uint32_t s = g_S.acc[v]; curDist = comp ? (uint32_t)(P.chroma_weight * (double)s) : s; curCost = rd_cost(P, g_S.iv_bits[v], curDist); }
+        else if (ts == 1) { curDist = 0; curCost = FCU_MAX_DOUBLE; }
+        else { curDist = nonDist; curCost = nonCost; }
+        if (curCost < minCost || (ts == 1 && curCost == minCost)) {
+          if (ts == 0 && (nonCost < curCost || curAbs == 0)) { curAbs = 0; curDist = nonDist; curCost = nonCost; }
+          bAbs = curAbs; bDist = curDist; minCost = curCost; bTs = ts;
+        }
+      }
+      g_S.it_abs[comp] = bAbs; g_S.it_ts[comp] = bTs; g_S.it_dist[comp] = bDist;
+    }
+  }
+  FCU_FOR_LANES {                                            /* publish the winners: levels (scan order), residual, flags */
+    for (int comp = 0; comp < ncomp; comp++) {
+      const int N = bN[comp], n2 = N * N, v = 2 * comp + g_S.it_ts[comp], o = voff(v), coded = g_S.it_abs[comp] > 0;
+      const int cgEnd = ((g_S.iv_top[v] >> 4) + 1) << 4;
+      int16_t *cf = G->qt_coef[comp][layer] + (comp ? tu.off_c : tu.off_y);
+      int16_t *rq = (comp == 0 ? G->qt_resi[layer].y + tu.y * 64 + tu.x : (comp == 1 ? G->qt_resi[layer].u : G->qt_resi[layer].v) + tu.cy * 32 + tu.cx);
+      for (int k = lane; k < n2; k += 64) {
+        cf[k] = (coded && k < cgEnd) ? G->p_qscan[o + k] : (int16_t)0;
+        rq[(k / N) * (comp ? 32 : 64) + k % N] = coded ? G->p_resi[2048 + o + k] : (int16_t)0;
+      }
+      const int cpart = comp ? tu_part_c(tu) : part, cnp = comp ? tu_nparts_c(tu) : tu.nparts;
+      for (int i = lane; i < cnp; i += 64) { cu->tskip[comp][cpart + i] = (uint8_t)g_S.it_ts[comp]; cu->cbf[comp][cpart + i] = (uint8_t)((coded ? 1 : 0) << trMode); }
+    }
+  }
+  FCU_SERIAL {                                               /* syntax of the whole TU from the snapshot: subdivision flag, cbf Cb Cr Y, coefficients Y Cb Cr */
+    const int c = CAB_GOON;
+    cab_reset_bits(c);
+    if (log2 > min_tu_log2_inter(d)) cab_bin(c, 0, CTX_SUBDIV + 5 - log2);
+    for (int k = 0; k < 3; k++) { const int comp = (k + 1) % 3; if (comp >= ncomp) continue; cab_bin(c, g_S.it_abs[comp] > 0, qt_cbf_ctx(tu, comp)); }
+    uint32_t dist = 0;
+    for (int comp = 0; comp < ncomp; comp++) {
+      if (g_S.it_abs[comp] > 0)
+        code_coeff_nxn<1>(c, G->qt_coef[comp][layer] + (comp ? tu.off_c : tu.off_y), 1, -1, bl2[comp], comp, 0, g_S.it_ts[comp], P, g_S.lane_abs[0]);
+      dist += g_S.it_dist[comp];
+    }
+    g_S.iv_bits[0] = cab_bits(c); g_S.iv_dist[0] = dist;
+  }
+  (void)depth;
+}
+
+/* ---- xEstimateInterResidualQT.  LEVEL = recursion level; adds (cost, bits, distortion) to g_S.iq_*[LEVEL]. */
+template <int LEVEL>
+FCU_DEV FCU_NOINLINE void est_inter_residual_qt(CuObj *cu, uint32_t tu_k, int addZero)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); const TU tu = tu_of_key(FCU_UNI(tu_k)); addZero = FCU_UNI(addZero);
+  const Params &P = E.C->p;
+  const int d = cu->depth_cu, part = tu.part, trMode = tu.tr_depth, depth = d + trMode, log2 = tu.log2;
+  const int checkFull = log2 <= LOG2_MAXTU, checkSplit = log2 > min_tu_log2_inter(d);
+  double singleCost = FCU_MAX_DOUBLE; uint32_t singleBits = 0, singleDist = 0;
+  int bestTS[3] = { 0, 0, 0 };
+  FCU_FOR_LANES cab_copy(slot_ptr(E, depth, CI_QT_TRAFO_ROOT), &g_S.cab[CAB_GOON], lane);
+  if (checkFull) {
+    inter_tu_trials(cu, tu_key(tu), addZero);
+    singleBits = FCU_UNI(g_S.iv_bits[0]); singleDist = FCU_UNI(g_S.iv_dist[0]);
+    singleCost = rd_cost(P, singleBits, singleDist);
+    for (int c = 0; c < 3; c++) bestTS[c] = FCU_UNI(g_S.it_ts[c]);
+  }
+  if (checkSplit) {
+    if constexpr (LEVEL < 2) {
+      if (checkFull) { FCU_FOR_LANES cab_copy(slot_ptr(E, depth, CI_QT_TRAFO_TEST), &g_S.cab[CAB_GOON], lane); FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, depth, CI_QT_TRAFO_ROOT), lane); }
+      int bestCbf[3];
+      for (int c = 0; c < 3; c++) bestCbf[c] = FCU_UNI((int)((cu->cbf[c][part] >> trMode) & 1));
+      FCU_SERIAL { g_S.iq_cost[LEVEL + 1] = 0; g_S.iq_bits[LEVEL + 1] = 0; g_S.iq_dist[LEVEL + 1] = 0; }
+      for (int i = 0; i < 4; i++) { TU c; tu_child(c, tu, i, 0); est_inter_residual_qt<LEVEL + 1>(cu, tu_key(c), checkFull ? 0 : addZero); }
+      const int q = tu.nparts >> 2;
+      FCU_SERIAL {
+        int any = 0;
+        for (int c = 0; c < 3; c++) { int yuv = 0; for (int i = 0; i < 4; i++) yuv |= (cu->cbf[c][part + i * q] >> (trMode + 1)) & 1; g_S.uni[c] = yuv; any |= yuv; }
+        g_S.uni[3] = any;
+      }
+      FCU_FOR_LANES { for (int c = 0; c < 3; c++) for (int o = lane; o < 4 * q; o += 64) cu->cbf[c][part + o] |= (uint8_t)(g_S.uni[c] << trMode); cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, depth, CI_QT_TRAFO_ROOT), lane); }
+      FCU_SERIAL {
+        cab_reset_bits(CAB_GOON);
+        encode_inter_residual_qt(CAB_GOON, cu, tu_key(tu), 3);
+        for (int c = 0; c < 3; c++) encode_inter_residual_qt(CAB_GOON, cu, tu_key(tu), c);
+        g_S.iv_bits[1] = cab_bits(CAB_GOON);
+      }
+      const uint32_t subBits = FCU_UNI(g_S.iv_bits[1]), subDist = FCU_UNI(g_S.iq_dist[LEVEL + 1]);
+      const double subCost = rd_cost(P, subBits, subDist);
+      const int cbfAny = FCU_UNI(g_S.uni[3]);
+      if (!checkFull || (cbfAny && subCost < singleCost)) { FCU_SERIAL { g_S.iq_cost[LEVEL] += subCost; g_S.iq_bits[LEVEL] += subBits; g_S.iq_dist[LEVEL] += subDist; } return; }
+      FCU_FOR_LANES {
+        for (int i = lane; i < tu.nparts; i += 64) { cu->tr_idx[part + i] = (uint8_t)trMode; for (int c = 0; c < 3; c++) { cu->cbf[c][part + i] = (uint8_t)(bestCbf[c] << trMode); cu->tskip[c][part + i] = (uint8_t)bestTS[c]; } }
+        cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, depth, CI_QT_TRAFO_TEST), lane);
+      }
+    }
+  }
+  FCU_SERIAL { g_S.iq_cost[LEVEL] += singleCost; g_S.iq_bits[LEVEL] += singleBits; g_S.iq_dist[LEVEL] += singleDist; }
+}
+
+/* xSetInterResidualQTData: leaves of the chosen tree -> CU levels (spatial 0) / residual samples (spatial 1); iterative */
+FCU_DEV FCU_NOINLINE void set_inter_residual_qt_data(CuObj *cu, int spatial)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); spatial = FCU_UNI(spatial);
+  Scratch *G = E.G;
+  TU *st = g_S.wk_st; int *ci = g_S.wk_ci; int sp = 0;
+  tu_root(st[0], cu->depth_cu); ci[0] = -1;
+  while (sp >= 0) {
+    const TU tu = st[sp];
+    if (ci[sp] < 0) {
+      if (tu.tr_depth == cu->tr_idx[tu.part]) {
+        const int layer = LOG2_MAXTU - tu.log2;
+        FCU_FOR_LANES {
+          for (int comp = 0; comp < 3; comp++) {
+            if (comp && tu.cw == 0) continue;
+            const int N = comp ? tu.cw : (1 << tu.log2), bs = comp ? 32 : 64, bx = comp ? tu.cx : tu.x, by = comp ? tu.cy : tu.y, off = comp ? tu.off_c : tu.off_y;
+            if (spatial) {
+              const int16_t *s = (comp == 0 ? G->qt_resi[layer].y : (comp == 1 ? G->qt_resi[layer].u : G->qt_resi[layer].v)) + by * bs + bx;
+              int16_t *t = (comp == 0 ? G->resi_best.y : (comp == 1 ? G->resi_best.u : G->resi_best.v)) + by * bs + bx;
+              for (int k = lane; k < N * N; k += 64) t[(k / N) * bs + k % N] = s[(k / N) * bs + k % N];
+            } else for (int k = lane; k < N * N; k += 64) cu->coef[comp][off + k] = G->qt_coef[comp][layer][off + k];
+          }
+        }
+        sp--; continue;
+      }
+      ci[sp] = 0;
+    }
+    if (ci[sp] >= 4) { sp--; continue; }
+    { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
+  }
+}
+
+/* ---- encodeResAndCalcRdInterCU: the prediction of the whole CU is in predt[d] */
+FCU_DEV FCU_NOINLINE void encode_res_and_calc_rd_inter_cu(CuObj *cu, int skipResidual)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); skipResidual = FCU_UNI(skipResidual);
+  Scratch *G = E.G; const Params &P = E.C->p;
+  const int d = cu->depth_cu, s = CTU >> d, n = cu->nparts, hs = s >> 1;
+  Yuv *org = &G->org[d], *pred = &G->predt[d], *rec = &G->reco[d][1 - g_S.reco_best_idx[d]];
+  if (skipResidual) {
+    FCU_FOR_LANES {
+      if (lane < 3) g_S.acc[lane] = 0;
+      for (int i = lane; i < n; i += 64) cu->skip[i] = 1;
+    }
+    FCU_FOR_LANES {
+      uint32_t e0 = 0, e1 = 0, e2 = 0;
+      for (int i = lane; i < s * s; i += 64) { const int o = (i / s) * 64 + i % s; const int v = pred->y[o]; rec->y[o] = (uint8_t)v; const int e = org->y[o] - v; e0 += (uint32_t)(e * e); }
+      for (int i = lane; i < hs * hs; i += 64) { const int o = (i / hs) * 32 + i % hs; int v = pred->u[o]; rec->u[o] = (uint8_t)v; int e = org->u[o] - v; e1 += (uint32_t)(e * e); v = pred->v[o]; rec->v[o] = (uint8_t)v; e = org->v[o] - v; e2 += (uint32_t)(e * e); }
+      FCU_WAVE_ADD(&g_S.acc[0], e0); FCU_WAVE_ADD(&g_S.acc[1], e1); FCU_WAVE_ADD(&g_S.acc[2], e2);
+    }
+    FCU_FOR_LANES cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
+    FCU_SERIAL {
+      cab_reset_bits(CAB_GOON);
+      code_skip_flag(E, CAB_GOON, cu, 0); code_merge_index(E, CAB_GOON, cu, 0);
+      cu->bits = cab_bits(CAB_GOON);
+      cu->dist = g_S.acc[0] + (uint32_t)(P.chroma_weight * (double)g_S.acc[1]) + (uint32_t)(P.chroma_weight * (double)g_S.acc[2]);
+      cu->cost = rd_cost(P, cu->bits, cu->dist);
+    }
+    FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane);
+    return;
+  }
+  FCU_FOR_LANES {                                            /* residual of the CU */
+    for (int i = lane; i < s * s; i += 64) { const int o = (i / s) * 64 + i % s; G->resi_cu.y[o] = (int16_t)(org->y[o] - pred->y[o]); }
+    for (int i = lane; i < hs * hs; i += 64) { const int o = (i / hs) * 32 + i % hs; G->resi_cu.u[o] = (int16_t)(org->u[o] - pred->u[o]); G->resi_cu.v[o] = (int16_t)(org->v[o] - pred->v[o]); }
+    cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
+    if (lane == 0) { g_S.iq_cost[0] = 0; g_S.iq_bits[0] = 0; g_S.iq_dist[0] = 0; g_S.iq_zero = 0; }
+  }
+  TU root; tu_root(root, d);
+  est_inter_residual_qt<0>(cu, tu_key(root), 1);
+  FCU_SERIAL {
+    cab_reset_bits(CAB_GOON); cab_bin(CAB_GOON, 0, CTX_ROOT_CBF);                            /* encodeQtRootCbfZero */
+    const double zeroCost = rd_cost(P, cab_bits(CAB_GOON), g_S.iq_zero);
+    g_S.uni[4] = (zeroCost < g_S.iq_cost[0] || !qt_root_cbf(cu, 0)) ? 1 : 0;
+  }
+  const int zeroOut = FCU_UNI(g_S.uni[4]);
+  if (zeroOut) { FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->tr_idx[i] = 0; for (int c = 0; c < 3; c++) { cu->cbf[c][i] = 0; cu->tskip[c][i] = 0; } } } }
+  else set_inter_residual_qt_data(cu, 0);
+  FCU_FOR_LANES {
+    cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
+    if (cu->merge_flag[0] && cu->part_size[0] == SIZE_2Nx2N && zeroOut) for (int i = lane; i < n; i += 64) cu->skip[i] = 1;   /* xAddSymbolBitsInter */
+  }
+  FCU_SERIAL { cab_reset_bits(CAB_GOON); encode_cu_syntax_inter(E, CAB_GOON, cu, 0, d); cu->bits = cab_bits(CAB_GOON); }
+  if (!zeroOut) set_inter_residual_qt_data(cu, 1);
+  FCU_FOR_LANES { cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); if (lane < 3) g_S.acc[lane] = 0; }
+  FCU_FOR_LANES {                                            /* reconstruction + final distortion */
+    uint32_t e0 = 0, e1 = 0, e2 = 0;
+    for (int i = lane; i < s * s; i += 64) { const int o = (i / s) * 64 + i % s; const int v = clip8(pred->y[o] + (zeroOut ? 0 : G->resi_best.y[o])); rec->y[o] = (uint8_t)v; const int e = org->y[o] - v; e0 += (uint32_t)(e * e); }
+    for (int i = lane; i < hs * hs; i += 64) {
+      const int o = (i / hs) * 32 + i % hs;
+      int v = clip8(pred->u[o] + (zeroOut ? 0 : G->resi_best.u[o])); rec->u[o] = (uint8_t)v; int e = org->u[o] - v; e1 += (uint32_t)(e * e);
+      v = clip8(pred->v[o] + (zeroOut ? 0 : G->resi_best.v[o])); rec->v[o] = (uint8_t)v; e = org->v[o] - v; e2 += (uint32_t)(e * e);
+    }
+    FCU_WAVE_ADD(&g_S.acc[0], e0); FCU_WAVE_ADD(&g_S.acc[1], e1); FCU_WAVE_ADD(&g_S.acc[2], e2);
+  }
+  FCU_SERIAL {
+    cu->dist = g_S.acc[0] + (uint32_t)(P.chroma_weight * (double)g_S.acc[1]) + (uint32_t)(P.chroma_weight * (double)g_S.acc[2]);
+    cu->cost = rd_cost(P, cu->bits, cu->dist);
+  }
+}

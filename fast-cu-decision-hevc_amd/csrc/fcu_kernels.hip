@@ -39,6 +39,24 @@ fcu_ctu_engine(Chain *chains, Scratch *scratch, int first, int ctus)
   run_chain(&chains[first + blockIdx.x], &scratch[first + blockIdx.x], ctus);
 }
 
+/* Reference picture padding (TComPicYuv::extendPicBorder): every thread writes 16 consecutive bytes of one row of a
+ * padded plane; the source coordinate is clamped into the picture.  HBM-bound: reads W*H*1.5, writes (W+160)*(H+160)*1.5/.. */
+__global__ void __launch_bounds__(256) fcu_pad_plane(const uint8_t *src, int w, int h, uint8_t *dst, int margin)
+{
+  const int pw = w + 2 * margin, ph = h + 2 * margin, chunks = (pw + 15) >> 4;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= chunks * ph) return;
+  const int y = t / chunks, x0 = (t - y * chunks) << 4;
+  int sy = y - margin; sy = sy < 0 ? 0 : (sy >= h ? h - 1 : sy);
+  const uint8_t *row = src + (size_t)sy * w;
+  uint8_t v[16];
+  const int sx0 = x0 - margin;
+  if (sx0 >= 0 && sx0 + 16 <= w) __builtin_memcpy(v, row + sx0, 16);
+  else for (int k = 0; k < 16; k++) { int sx = sx0 + k; sx = sx < 0 ? 0 : (sx >= w ? w - 1 : sx); v[k] = row[sx]; }
+  uint8_t *o = dst + (size_t)y * pw + x0;
+  if (x0 + 16 <= pw) __builtin_memcpy(o, v, 16); else for (int k = 0; x0 + k < pw; k++) o[k] = v[k];
+}
+
 /* ---------------------------------------------------------------------------------------- */
 struct fcu_ctx {
   fcu_seq_params sp;
@@ -130,6 +148,8 @@ int fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
 {
   if (!c || !fp || chain < 0 || chain >= c->sp.max_chains || !oy || !ou || !ov || !ry || !ru || !rv || !dev_out) return fail(FCU_ERR_ARG, "fcu_chain_begin: bad argument");
   if (fp->qp < 0 || fp->qp > 51 || fp->slice_ctus < 0) return fail(FCU_ERR_ARG, "fcu_chain_begin: QP / slice_ctus out of range");
+  if (fp->slice_type != FCU_SLICE_I && fp->slice_type != FCU_SLICE_P) return fail(FCU_ERR_ARG, "fcu_chain_begin: unknown slice type");
+  if (fp->slice_type == FCU_SLICE_P && (!(fp->lambda > 0.0) || fp->search_range < 1 || fp->search_range > 64)) return fail(FCU_ERR_ARG, "fcu_chain_begin: a P slice needs its lambda (fcu_ldp_slice) and 1 <= search_range <= 64");
   HIPCHK(hipSetDevice(c->sp.device));
   Chain &h = c->h_chains[(size_t)chain];
   memset(&h, 0, sizeof(h));
@@ -141,6 +161,45 @@ int fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
   h.next_ctu = 0; h.end_ctu = h.n_ctu;
   c->h_pos[(size_t)chain] = 0;
   HIPCHK(hipMemcpy(&c->d_chains[chain], &h, sizeof(Chain), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+void fcu_ldp_slice(fcu_frame_params *fp, int base_qp, int poc) { if (fp) ldp_slice(*fp, base_qp, poc); }
+
+void fcu_pad_sizes(const fcu_ctx *c, size_t *out3)
+{
+  if (!c || !out3) return;
+  out3[0] = (size_t)(c->sp.width + 2 * FCU_REF_MARGIN) * (size_t)(c->sp.height + 2 * FCU_REF_MARGIN);
+  out3[1] = out3[2] = (size_t)(c->sp.width / 2 + FCU_REF_MARGIN) * (size_t)(c->sp.height / 2 + FCU_REF_MARGIN);
+}
+
+int fcu_pad_reference(fcu_ctx *c, const uint8_t *dy, const uint8_t *du, const uint8_t *dv, uint8_t *py, uint8_t *pu, uint8_t *pv, void *hip_stream)
+{
+  if (!c || !dy || !du || !dv || !py || !pu || !pv) return fail(FCU_ERR_ARG, "fcu_pad_reference: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const uint8_t *src[3] = { dy, du, dv }; uint8_t *dst[3] = { py, pu, pv };
+  for (int k = 0; k < 3; k++) {
+    const int w = k ? c->sp.width / 2 : c->sp.width, h = k ? c->sp.height / 2 : c->sp.height, m = k ? FCU_REF_MARGIN / 2 : FCU_REF_MARGIN;
+    const int n = ((w + 2 * m + 15) >> 4) * (h + 2 * m);
+    hipLaunchKernelGGL(fcu_pad_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src[k], w, h, dst[k], m);
+    HIPCHK(hipGetLastError());
+  }
+  return FCU_OK;
+}
+
+int fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *py, const uint8_t *pu, const uint8_t *pv)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !py || !pu || !pv) return fail(FCU_ERR_ARG, "fcu_chain_set_reference: bad argument");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_reference: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  const int m = FCU_REF_MARGIN, sy = c->sp.width + 2 * m, sc = c->sp.width / 2 + m;
+  h.ref_stride[0] = sy; h.ref_stride[1] = h.ref_stride[2] = sc;
+  h.ref[0] = py + (size_t)m * sy + m; h.ref[1] = pu + (size_t)(m / 2) * sc + m / 2; h.ref[2] = pv + (size_t)(m / 2) * sc + m / 2;
+  static_assert(offsetof(Chain, ref_stride) == offsetof(Chain, ref) + 3 * sizeof(void *), "ref / ref_stride are adjacent");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, ref), &h.ref[0], 3 * sizeof(void *) + 3 * sizeof(int), hipMemcpyHostToDevice));
   return FCU_OK;
 }
 
@@ -167,7 +226,10 @@ int fcu_chain_set_range(fcu_ctx *c, int chain, int first_ctu, int n_ctus)
 int fcu_compress_chains(fcu_ctx *c, int first, int n, int ctus, void *hip_stream)
 {
   if (!c || first < 0 || n <= 0 || first + n > c->sp.max_chains || ctus <= 0) return fail(FCU_ERR_ARG, "fcu_compress_chains: bad range");
-  for (int i = first; i < first + n; i++) if (c->h_chains[(size_t)i].out == nullptr) return fail(FCU_ERR_STATE, "fcu_compress_chains: chain not bound (fcu_chain_begin)");
+  for (int i = first; i < first + n; i++) {
+    if (c->h_chains[(size_t)i].out == nullptr) return fail(FCU_ERR_STATE, "fcu_compress_chains: chain not bound (fcu_chain_begin)");
+    if (c->h_chains[(size_t)i].p.slice_type == SLICE_P && c->h_chains[(size_t)i].ref[0] == nullptr) return fail(FCU_ERR_STATE, "fcu_compress_chains: P chain without reference picture (fcu_chain_set_reference)");
+  }
   HIPCHK(hipSetDevice(c->sp.device));
   hipStream_t st = (hipStream_t)hip_stream;
   hipEvent_t e0, e1;
@@ -240,6 +302,18 @@ int fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bit
   Chain h;
   HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
   memcpy(ctx160, h.state.ctx, NCTX_INTRA);
+  *frac_bits = h.state.frac;
+  return FCU_OK;
+}
+
+int fcu_get_ctx_state_full(fcu_ctx *c, int chain, uint8_t *ctx176, uint64_t *frac_bits)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !ctx176 || !frac_bits) return fail(FCU_ERR_ARG, "fcu_get_ctx_state_full: bad argument");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  Chain h;
+  HIPCHK(hipMemcpy(&h, &c->d_chains[chain], sizeof(Chain), hipMemcpyDeviceToHost));
+  memcpy(ctx176, h.state.ctx, NCTX);
   *frac_bits = h.state.frac;
   return FCU_OK;
 }

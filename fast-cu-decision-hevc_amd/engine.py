@@ -26,7 +26,9 @@ class FrameParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("slice_ctus", C.c_int), ("transform_skip", C.c_int),
                 ("transform_skip_fast", C.c_int), ("sign_hiding", C.c_int), ("strong_intra_smoothing", C.c_int),
                 ("lambda_", C.c_double), ("sqrt_lambda", C.c_double), ("chroma_weight", C.c_double),
-                ("rdoq_lambda", C.c_double * 3)]
+                ("rdoq_lambda", C.c_double * 3),
+                ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_enc", C.c_int), ("hadamard_me", C.c_int),
+                ("fast_merge_decision", C.c_int), ("max_merge_cand", C.c_int)]
 
 
 class SeqParams(C.Structure):
@@ -67,7 +69,10 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
-           "fcu_build_info", "fcu_tcm_threshold"]
+           "fcu_build_info", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full"]
+
+SLICE_I, SLICE_P = 0, 1
+REF_MARGIN = 80
 
 
 def lib_path():
@@ -98,6 +103,7 @@ def load_lib():
     lib.fcu_obf_prepass.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
     lib.fcu_compress_ctu.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(CtuOut)]
     lib.fcu_get_ctx_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.fcu_get_ctx_state_full.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.fcu_chain_position.argtypes = [C.c_void_p, C.c_int]
     lib.fcu_sync.argtypes = [C.c_void_p]
     lib.fcu_kernel_ms.restype = C.c_double
@@ -107,6 +113,12 @@ def load_lib():
     lib.fcu_build_info.restype = C.c_char_p
     lib.fcu_tcm_threshold.restype = C.c_double
     lib.fcu_tcm_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fcu_chain_set_reference.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_pad_reference.argtypes = [C.c_void_p] * 8
+    lib.fcu_pad_sizes.restype = None
+    lib.fcu_pad_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.fcu_ldp_slice.restype = None
+    lib.fcu_ldp_slice.argtypes = [C.POINTER(FrameParams), C.c_int, C.c_int]
     lib.fcu_chain_set_decision.argtypes = [C.c_void_p, C.c_int, C.POINTER(DecisionParams)]
     lib.fcu_get_verify_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(VerifyCounts)]
     lib.fcu_decision_switch.restype = None
@@ -130,6 +142,13 @@ def decision_switch(ver, th_skip=(0, 0, 0, 0), th_term=(0, 0, 0, 0)):
     sk, te = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
     lib.fcu_decision_switch(C.byref(v), ts.ctypes.data, tt.ctypes.data, sk.ctypes.data, te.ctypes.data)
     return sk, te
+
+
+def ldp_slice(base_qp, poc):
+    """FrameParams of picture `poc` under HM's lowdelay_P GOP table (fcu_ldp_slice): slice type, QP, lambda, inter defaults."""
+    fp = FrameParams()
+    load_lib().fcu_ldp_slice(C.byref(fp), base_qp, poc)
+    return fp
 
 
 def frame_state(poc, period=60, n_training=2, n_verifying=1):
@@ -165,6 +184,7 @@ class CuEngine:
         self.h = C.c_void_p()
         self._keep = {}
         self._keep_obf = {}
+        self._keep_ref = {}
         self.create()
 
     # -- TEncCu::create
@@ -180,8 +200,10 @@ class CuEngine:
             raise FcuError(f"{what} failed ({r}): {self.lib.fcu_last_error().decode()}")
 
     # -- TEncCu::init + slice parameters
-    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, **flags):
-        """org: (Y,U,V) uint8 torch tensors on this device (or numpy arrays, uploaded once)."""
+    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, ref=None, params=None, **flags):
+        """org: (Y,U,V) uint8 torch tensors on this device (or numpy arrays, uploaded once).
+        params: a FrameParams to start from (e.g. ldp_slice(base_qp, poc)) instead of the I-slice defaults for `qp`;
+        ref: padded reference planes from pad_reference() -- required for a P slice."""
         torch = self.torch
         dev = torch.device("cuda", self.device)
         planes = []
@@ -193,7 +215,10 @@ class CuEngine:
         if out is None:
             out = torch.zeros(self.n_ctu * CTU_OUT_BYTES, dtype=torch.uint8, device=dev)
         fp = FrameParams()
-        self.lib.fcu_default_frame_params(C.byref(fp), qp)
+        if params is not None:
+            C.memmove(C.byref(fp), C.byref(params), C.sizeof(FrameParams))
+        else:
+            self.lib.fcu_default_frame_params(C.byref(fp), qp)
         fp.slice_ctus = slice_ctus
         known = {n for n, _ in FrameParams._fields_}
         for k, v in flags.items():
@@ -203,7 +228,23 @@ class CuEngine:
         self._chk(self.lib.fcu_chain_begin(self.h, chain, C.byref(fp), *[p.data_ptr() for p in planes],
                                            *[p.data_ptr() for p in rec], out.data_ptr()), "fcu_chain_begin")
         self._keep[chain] = (planes, rec, out)
+        if ref is not None:
+            self._chk(self.lib.fcu_chain_set_reference(self.h, chain, *[p.data_ptr() for p in ref]), "fcu_chain_set_reference")
+            self._keep_ref[chain] = ref
         return rec, out
+
+    def pad_reference(self, planes, stream=None):
+        """(Y, U, V) device planes of a reconstructed (loop-filtered) picture -> padded planes for P chains
+        (TComPicYuv::extendPicBorder).  Returns three uint8 tensors."""
+        torch = self.torch
+        sz = (C.c_size_t * 3)()
+        self.lib.fcu_pad_sizes(self.h, sz)
+        dev = torch.device("cuda", self.device)
+        src = [torch.as_tensor(p).to(device=dev, dtype=torch.uint8).contiguous() for p in planes]
+        out = [torch.empty(int(sz[k]), dtype=torch.uint8, device=dev) for k in range(3)]
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._chk(self.lib.fcu_pad_reference(self.h, *[p.data_ptr() for p in src], *[p.data_ptr() for p in out], s), "fcu_pad_reference")
+        return out
 
     def init_slice_chains(self, first_chain, org, qp, slice_ctus, **flags):
         """One frame as ceil(n_ctu / slice_ctus) chains, one per slice (SliceMode 1): they share the frame's
@@ -247,10 +288,14 @@ class CuEngine:
     def position(self, chain):
         return self.lib.fcu_chain_position(self.h, chain)
 
-    def ctx_state(self, chain):
-        ctx = np.zeros(160, np.uint8)
+    def ctx_state(self, chain, full=False):
+        """context states after the chain's last CTU: the 160 of an I slice, or all 176 (full=True), + the Q15 counter"""
+        ctx = np.zeros(176 if full else 160, np.uint8)
         frac = C.c_uint64(0)
-        self._chk(self.lib.fcu_get_ctx_state(self.h, chain, ctx.ctypes.data, C.byref(frac)), "fcu_get_ctx_state")
+        if full:
+            self._chk(self.lib.fcu_get_ctx_state_full(self.h, chain, ctx.ctypes.data, C.byref(frac)), "fcu_get_ctx_state_full")
+        else:
+            self._chk(self.lib.fcu_get_ctx_state(self.h, chain, ctx.ctypes.data, C.byref(frac)), "fcu_get_ctx_state")
         return ctx, int(frac.value)
 
     def rec_planes(self, chain):

@@ -1,0 +1,67 @@
+"""Host driver of the P-slice path (BASELINE configs[4], lowdelay_P): what TEncGOP::compressGOP does around the CU
+decision for a clip whose pictures reference the previous reconstructed picture (TEncGOP.cpp:1096-1160 per picture:
+slice parameters -> compressSlice -> loop filter -> reference for the next picture).
+
+Pictures of ONE clip are strictly sequential (every P picture needs the filtered reconstruction of its predecessor), so
+the parallelism of a launch comes from the slices of a picture and from independent clips side by side: clip s, slice k
+is chain s * n_slices + k.  Per picture: fcu_ldp_slice (QP / lambda of HM's lowdelay_P GOP table) -> fcu_chain_begin
+(+ fcu_chain_set_reference for P) -> one fcu_compress_chains launch over all chains -> fcu_deblock -> fcu_pad_reference.
+Across GPUs the reference picture is the only data a rank would need from another one (one copy per picture);
+with whole clips per rank there is none.
+"""
+import numpy as np
+
+from . import engine as _engine
+
+
+class LowDelayPDecider:
+    """`n_clips` clips of width x height decided picture by picture on one GPU.
+    slice_ctus: CTUs per slice (HM SliceMode 1); None = one slice per picture (the reference configuration)."""
+
+    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, device=0):
+        self.width, self.height, self.base_qp, self.n_clips, self.search_range = width, height, base_qp, n_clips, search_range
+        n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
+        self.slice_ctus = slice_ctus if slice_ctus else n_ctu
+        self.n_slices = (n_ctu + self.slice_ctus - 1) // self.slice_ctus
+        self.eng = _engine.CuEngine(width, height, max_chains=n_clips * self.n_slices, device=device)
+        self.do_deblock = deblock
+        self.poc = 0
+        self.ref = [None] * n_clips                      # padded reference planes per clip
+
+    def frame_params(self, poc):
+        fp = _engine.ldp_slice(self.base_qp, poc)
+        fp.search_range = self.search_range
+        return fp
+
+    def decide_picture(self, frames):
+        """frames: one (Y, U, V) per clip for picture self.poc.  Returns per clip a dict: poc, slice_type, qp, `out` (the
+        fcu_ctu_out array as a uint8 device tensor), `rec` (device planes, deblocked when enabled), `rec_unfiltered`
+        (a copy before the loop filter, for parity checks)."""
+        eng, poc = self.eng, self.poc
+        assert len(frames) == self.n_clips
+        fp = self.frame_params(poc)
+        res = []
+        for s, f in enumerate(frames):
+            first = s * self.n_slices
+            ref = self.ref[s] if fp.slice_type == _engine.SLICE_P else None
+            rec, out = eng.init_chain(first, f, fp.qp, slice_ctus=self.slice_ctus if self.n_slices > 1 else 0, params=fp, ref=ref)
+            planes = eng._keep[first][0]
+            for k in range(self.n_slices):
+                if k:
+                    eng.init_chain(first + k, planes, fp.qp, slice_ctus=self.slice_ctus, rec=rec, out=out, params=fp, ref=ref)
+                if self.n_slices > 1:
+                    a = k * self.slice_ctus
+                    eng.set_range(first + k, a, min(self.slice_ctus, eng.n_ctu - a))
+            res.append({"poc": poc, "slice_type": fp.slice_type, "qp": fp.qp, "lambda": fp.lambda_, "out": out, "rec": rec, "first": first})
+        eng.compress_chains(0, self.n_clips * self.n_slices, self.slice_ctus)
+        for s, r in enumerate(res):
+            r["rec_unfiltered"] = [p.clone() for p in r["rec"]]
+            if self.do_deblock:
+                eng.deblock(r["first"])
+            self.ref[s] = eng.pad_reference(r["rec"])          # reference of the next picture of this clip
+        eng.sync()
+        self.poc += 1
+        return res
+
+    def close(self):
+        self.eng.destroy()

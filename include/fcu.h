@@ -76,9 +76,19 @@ typedef struct fcu_frame_params {
   int qp;                        /* slice QP                                                 */
   int slice_ctus;                /* SliceMode 1 / SliceArgument (CTUs per slice); 0 = 1 slice */
   int transform_skip, transform_skip_fast, sign_hiding, strong_intra_smoothing;
-  /* 0.0 => derive as HM does for an I slice (TEncSlice.cpp:686-706, 496-524) */
+  /* 0.0 => derive as HM does for an I slice (TEncSlice.cpp:686-706, 496-524); a P slice must give lambda (its GOP
+   * entry's QP factor, fcu_ldp_slice), sqrt_lambda / chroma_weight / rdoq_lambda are then derived from it when left 0 */
   double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
+  /* P slices (lowdelay_P, BASELINE configs[4]); all 0 in an I slice */
+  int slice_type;                /* FCU_SLICE_I / FCU_SLICE_P: a P chain needs fcu_chain_set_reference                   */
+  int search_range;              /* SearchRange in integer samples (64); the search is HM's full search (FastSearch 0)  */
+  int fast_enc;                  /* FEN: every other row in the integer-search SAD of blocks taller than 8              */
+  int hadamard_me;               /* HadamardME: SATD in the sub-sample refinement and the merge estimation              */
+  int fast_merge_decision;       /* FDM                                                                                  */
+  int max_merge_cand;            /* MaxNumMergeCand (5)                                                                  */
 } fcu_frame_params;
+enum { FCU_SLICE_I = 0, FCU_SLICE_P = 1 };
+#define FCU_REF_MARGIN_LUMA 80   /* border of a padded reference plane: g_uiMaxCUWidth + 16 (TComPic::create); chroma: 40 */
 
 typedef struct fcu_ctx fcu_ctx;
 
@@ -91,6 +101,21 @@ int  fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
                      const uint8_t *dev_org_y, const uint8_t *dev_org_u, const uint8_t *dev_org_v,
                      uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
                      fcu_ctu_out *dev_out);
+/* P slice: the reference picture of the chain (list 0, index 0) = the previous picture after the loop filters, as padded
+ * planes made by fcu_pad_reference (pointers to the first byte of each padded plane; luma stride = width + 2 * 80).
+ * Slice QP and lambda of picture `poc` under HM's lowdelay_P GOP table come from fcu_ldp_slice. */
+int  fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *dev_pad_y, const uint8_t *dev_pad_u, const uint8_t *dev_pad_v);
+/* Reference picture padding (TComPicYuv::extendPicBorder): copies the width x height planes into planes of
+ * (width + 160) x (height + 160) luma / (width/2 + 80) x (height/2 + 80) chroma samples with the border replicated.
+ * One kernel on `hip_stream`, asynchronous. */
+int  fcu_pad_reference(fcu_ctx *c, const uint8_t *dev_y, const uint8_t *dev_u, const uint8_t *dev_v,
+                       uint8_t *dev_pad_y, uint8_t *dev_pad_u, uint8_t *dev_pad_v, void *hip_stream);
+/* bytes of the three padded planes of this sequence: out3[0] luma, out3[1] = out3[2] chroma */
+void fcu_pad_sizes(const fcu_ctx *c, size_t *out3);
+/* Slice type, QP and lambda of picture `poc` under HM's encoder_lowdelay_P_main GOP table (QP offsets 3,2,3,1; QP factors
+ * 0.4624 x3, 0.578) as TEncSlice::initEncSlice derives them (TEncSlice.cpp:560-740): fills fp->qp / lambda / slice_type and the
+ * configuration defaults (SearchRange 64, FEN, HadamardME, FDM, MaxNumMergeCand 5).  Pure host arithmetic. */
+void fcu_ldp_slice(fcu_frame_params *fp, int base_qp, int poc);
 /* Restrict a bound chain to the CTUs [first_ctu, first_ctu + n_ctus) of its frame.  Both ends must be slice
  * boundaries (frame_params.slice_ctus), where HM resets the entropy coder (TEncSlice.cpp:1392-1395) and masks the
  * neighbourhood (TComDataCU::getPULeft/Above): the slices of ONE frame then run as independent chains that share
@@ -105,6 +130,8 @@ int  fcu_compress_ctu(fcu_ctx *c, int chain, uint32_t ctuRsAddr, fcu_ctu_out *ho
 /* context state of m_pppcRDSbacCoder[0][CI_CURR_BEST] after the chain's last CTU:
  * 160 context bytes (engine order, see fcu_engine.h) + the Q15 fractional bit counter */
 int  fcu_get_ctx_state(fcu_ctx *c, int chain, uint8_t *ctx160, uint64_t *frac_bits);
+/* all 176 context states (160 residual / intra contexts + the inter syntax, engine order) + the Q15 counter */
+int  fcu_get_ctx_state_full(fcu_ctx *c, int chain, uint8_t *ctx176, uint64_t *frac_bits);
 int  fcu_chain_position(fcu_ctx *c, int chain);          /* next CTU to be decided */
 int  fcu_sync(fcu_ctx *c);
 /* average duration (ms) of the engine kernel launches recorded with HIP events on the launch

@@ -31,6 +31,27 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, int tools, c
   e->g = (Scratch *)calloc(1, sizeof(Scratch));
   return e;
 }
+/* P picture: lambda of the slice (fcu_ldp_slice on the host), search range, and the padded reference planes
+ * (luma margin FCU_REF_MARGIN, pointers to the first byte of each padded plane) */
+void fcu_emu_set_p(void *h, int qp, double lambda, int search_range, const uint8_t *py, const uint8_t *pu, const uint8_t *pv)
+{
+  EmuChain *e = (EmuChain *)h;
+  const int width = e->c.p.width, height = e->c.p.height;
+  fcu_frame_params fp; default_frame_params(fp, qp);
+  fp.slice_ctus = e->c.p.slice_ctus; fp.slice_type = FCU_SLICE_P; fp.lambda = lambda; fp.search_range = search_range;
+  fill_params(e->c.p, width, height, fp);
+  const int m = FCU_REF_MARGIN, sy = width + 2 * m, sc = width / 2 + m;
+  e->c.ref_stride[0] = sy; e->c.ref_stride[1] = e->c.ref_stride[2] = sc;
+  e->c.ref[0] = py + (size_t)m * sy + m; e->c.ref[1] = pu + (size_t)(m / 2) * sc + m / 2; e->c.ref[2] = pv + (size_t)(m / 2) * sc + m / 2;
+}
+/* lambda of an I picture that is not the intra_main default (lowdelay_P: 0.57 * 0.85) */
+void fcu_emu_set_lambda(void *h, int qp, double lambda)
+{
+  EmuChain *e = (EmuChain *)h;
+  fcu_frame_params fp; default_frame_params(fp, qp); fp.slice_ctus = e->c.p.slice_ctus; fp.lambda = lambda;
+  fill_params(e->c.p, e->c.p.width, e->c.p.height, fp);
+}
+void fcu_emu_get_state_full(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX); *frac = e->c.state.frac; }
 void fcu_emu_destroy(void *h) { EmuChain *e = (EmuChain *)h; free(e->g); delete e; }
 void fcu_emu_compress_ctu(void *h, int a) { EmuChain *e = (EmuChain *)h; compress_ctu(&e->c, e->g, a); e->c.next_ctu = a + 1; }
 void fcu_emu_get_state(void *h, uint8_t *ctx, uint64_t *frac) { EmuChain *e = (EmuChain *)h; memcpy(ctx, e->c.state.ctx, NCTX_INTRA); *frac = e->c.state.frac; }

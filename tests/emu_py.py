@@ -20,11 +20,23 @@ def load():
     lib.fcu_emu_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.fcu_emu_tu_trials.restype = C.c_ulonglong
     lib.fcu_emu_tu_trials.argtypes = [C.c_void_p]
+    lib.fcu_emu_set_p.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_emu_set_lambda.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.fcu_emu_get_state_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
+REF_MARGIN = 80
+
+
+def pad_planes(planes):
+    """numpy twin of fcu_pad_reference (TComPicYuv::extendPicBorder): border replicated 80 / 40 samples"""
+    return [np.ascontiguousarray(np.pad(p, REF_MARGIN >> (1 if k else 0), mode="edge")) for k, p in enumerate(planes)]
+
+
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64):
+        """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda)"""
         self.lib = load()
         h, w = Y.shape
         self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
@@ -33,6 +45,11 @@ class EmuEncoder:
         self.out = (Ctu * self.n_ctu)()
         self.h = self.lib.fcu_emu_create(w, h, qp, slice_ctus, tools, *[a.ctypes.data for a in self.org],
                                          *[a.ctypes.data for a in self.rec], C.addressof(self.out))
+        if ref is not None:
+            self.pad = pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in ref])
+            self.lib.fcu_emu_set_p(self.h, qp, float(lam), search_range, *[a.ctypes.data for a in self.pad])
+        elif lam is not None:
+            self.lib.fcu_emu_set_lambda(self.h, qp, float(lam))
 
     def compress_ctu(self, a):
         self.lib.fcu_emu_compress_ctu(self.h, a)
@@ -60,8 +77,8 @@ class EmuEncoder:
             res[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
         return res
 
-    def cabac(self):
-        ctx = np.zeros(160, np.uint8)
+    def cabac(self, full=False):
+        ctx = np.zeros(176 if full else 160, np.uint8)
         frac = C.c_uint64(0)
-        self.lib.fcu_emu_get_state(self.h, ctx.ctypes.data, C.byref(frac))
+        (self.lib.fcu_emu_get_state_full if full else self.lib.fcu_emu_get_state)(self.h, ctx.ctypes.data, C.byref(frac))
         return ctx, int(frac.value)

@@ -1,0 +1,114 @@
+"""GPU parity of the P-slice path (BASELINE configs[4]): the HIP engine through the C ABI against the oracle (which is
+pinned candidate by candidate by the reference's own inter search, tests/test_golden_inter.py) -- every fcu_ctu_out field
+incl. motion, the reconstruction, the CABAC state, the deblocked pictures; and the deblocked pictures of the 416x240 clip
+against the CRCs the reference's own loop filter produced (tests/golden/inter_smooth416_qp32.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+import hmo_py
+import search_trace as st
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same_ctu(got, want, tag):
+    for k, v in want.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, got[k]), f"{tag}: field {k} differs at {np.argwhere(v != got[k])[:4].tolist()}"
+        else:
+            assert v == got[k], f"{tag}: {k}: engine {got[k]} oracle {v}"
+
+
+@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr", [("mixed", 136, 72, 27, 3, 8), ("textured", 192, 128, 32, 3, 16), ("smooth", 128, 64, 37, 5, 64)])
+def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr):
+    """compressCtu-shaped calls: every CTU of every picture of a short lowdelay_P clip, CABAC state after every CTU."""
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    prev, prev_pad = None, None
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, 5, poc)
+        fp = pkg.engine.ldp_slice(base_qp, poc)
+        fp.search_range = sr
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        assert fp.qp == qp and fp.lambda_ == lam and fp.slice_type == (0 if poc == 0 else 1)
+        eng.init_chain(0, f, fp.qp, params=fp, ref=prev_pad)
+        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+        for a in range(eng.n_ctu):
+            got = eng.compress_ctu(0, a)
+            ref.compress_ctu(a)
+            _same_ctu(got, ref.ctu_arrays(a), f"{gen} poc{poc} ctu{a}")
+            (ce, fe), (co, fo) = eng.ctx_state(0, full=True), ref.cabac(full=True)
+            assert fe == fo and np.array_equal(ce[st.O_SORTED], co[st.O_SORTED]), f"CABAC state poc{poc} ctu{a}"
+        for p, q in zip(eng.rec_planes(0), ref.rec):
+            assert np.array_equal(p, q), f"reconstruction poc{poc}"
+        eng.deblock(0)
+        eng.sync()
+        ref.deblock()
+        for p, q in zip(eng.rec_planes(0), ref.rec):
+            assert np.array_equal(p, q), f"deblocked picture poc{poc}"
+        prev = [a.copy() for a in ref.rec]
+        prev_pad = eng.pad_reference(eng._keep[0][1])
+        import emu_py
+        for t, q in zip(prev_pad, emu_py.pad_planes(prev)):       # fcu_pad_reference == replicated border
+            assert np.array_equal(t.cpu().numpy(), q.ravel())
+    eng.destroy()
+
+
+def test_ldp_416x240_clip_matches_oracle_and_reference_loop_filter(pkg):
+    """The >= 3-picture 416x240 lowdelay_P clip of the golden fixture through the batched driver (one launch per picture)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgi", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    gen, w, h, base_qp, seed, n_pic, sr = m.CASES["smooth416_qp32"]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "inter_smooth416_qp32.npz"))
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr)
+    prev = None
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        r = dec.decide_picture([f])[0]
+        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+        ref.compress_frame()
+        for a in range(ref.n_ctu):
+            _same_ctu(dec.eng.ctu_out(0, a), ref.ctu_arrays(a), f"poc{poc} ctu{a}")
+        for p, q in zip(r["rec_unfiltered"], ref.rec):
+            assert np.array_equal(p.cpu().numpy(), q)
+        ref.deblock()
+        planes = [p.cpu().numpy() for p in r["rec"]]
+        for p, q in zip(planes, ref.rec):
+            assert np.array_equal(p, q)
+        if poc:
+            assert [st.crc(p) for p in planes] == [int(v) for v in g[f"deblock_{poc}"][:3]], "deblocked P picture vs the reference's own loop filter"
+        prev = [a.copy() for a in ref.rec]
+    dec.close()
+
+
+def test_4k_pair_ctu_rows(pkg):
+    """BASELINE configs[4] at full size: a 3840x2160 picture pair.  Picture 0 (intra) is decided, deblocked and padded on
+    the GPU (that path has its own 4K parity test); picture 1 (P, one CTU row per slice, SearchRange 16 to bound the
+    oracle's CPU time) is compared with the oracle on the top row, an interior row and the partial bottom row."""
+    w, h, base_qp, sr, sl = 3840, 2160, 32, 16, 60
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl)
+    f0 = st.moving_frame(pkg.synth, "textured", w, h, 7, 0)
+    r0 = dec.decide_picture([f0])[0]
+    prev = [p.cpu().numpy() for p in r0["rec"]]
+    f1 = st.moving_frame(pkg.synth, "textured", w, h, 7, 1)
+    r1 = dec.decide_picture([f1])[0]
+    _, qp, lam = hmo_py.ldp_slice(1, base_qp)
+    ref = hmo_py.Encoder(*f1, qp, slice_ctus=sl, ref=prev, lambda_override=lam, search_range=sr)
+    n_inter = 0
+    for row in (0, 17, 33):
+        for a in range(row * 60, row * 60 + 60):
+            ref.compress_ctu(a)
+            want = ref.ctu_arrays(a)
+            _same_ctu(dec.eng.ctu_out(0, a), want, f"4K P picture ctu{a}")
+            n_inter += int((want["pred_mode"] == 0).sum())
+        y0, y1 = row * 64, min(h, row * 64 + 64)
+        for k, (p, q) in enumerate(zip(r1["rec_unfiltered"], ref.rec)):
+            a0, a1 = (y0 >> (1 if k else 0)), (y1 >> (1 if k else 0))
+            assert np.array_equal(p.cpu().numpy()[a0:a1], q[a0:a1]), f"reconstruction rows of CTU row {row}"
+    assert n_inter > 0
+    dec.close()

@@ -1,0 +1,65 @@
+"""P pictures through the ENGINE SOURCE on the CPU wave emulator (tests/emu, test-only build of csrc/fcu_engine.h +
+fcu_inter.h) and the deblocking kernel source compiled for the CPU (tests/emu/dbk_emu.cpp): every fcu_ctu_out field,
+the reconstruction and the CABAC state against the oracle CTU by CTU, and every deblocked P picture against the CRC the
+REFERENCE's own TComLoopFilter produced for the same clip (tests/golden/inter_*.npz)."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import emu_py
+import hmo_py
+import search_trace as st
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cases():
+    spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.CASES
+
+
+def dbk_emu(out_arr, rec, w, h, beta=0, tc=0):
+    lib = C.CDLL(os.path.join(ROOT, "tests", "emu", "libdbk_emu.so"))
+    lib.dbk_emu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
+    lib.dbk_emu(C.addressof(out_arr), rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, w, h, beta, tc)
+
+
+@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37"])
+def test_emulated_engine_p_pictures(case, built, pkg):
+    gen, w, h, base_qp, seed, n_pic, sr = _cases()[case]
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
+    prev = None
+    n_inter = n_skip = 0
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        if poc == 0:
+            o, e = hmo_py.Encoder(*f, qp, lambda_override=lam), emu_py.EmuEncoder(*f, qp, lam=lam)
+        else:
+            o = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr)
+        for a in range(o.n_ctu):
+            o.compress_ctu(a)
+            e.compress_ctu(a)
+            A, B = o.ctu_arrays(a), e.ctu_arrays(a)
+            for k, v in A.items():
+                assert (np.array_equal(v, B[k]) if isinstance(v, np.ndarray) else v == B[k]), (poc, a, k)
+            (ca, fa), (cb, fb) = o.cabac(full=True), e.cabac(full=True)
+            assert fa == fb and np.array_equal(ca[st.O_SORTED], cb[st.O_SORTED]), (poc, a, "CABAC state")
+            n_inter += int((A["pred_mode"] == 0).sum())
+            n_skip += int(A["skip"].sum())
+        for p, q in zip(o.rec, e.rec):
+            assert np.array_equal(p, q), (poc, "reconstruction")
+        dbk_emu(e.out, e.rec, w, h)                              # kernel source on the CPU, in place
+        if poc:
+            assert [st.crc(p) for p in e.rec] == [int(v) for v in g[f"deblock_{poc}"][:3]], (poc, "deblocked picture vs the reference's loop filter")
+        o.deblock()
+        for p, q in zip(o.rec, e.rec):
+            assert np.array_equal(p, q), (poc, "deblocked picture vs oracle")
+        prev = [a.copy() for a in e.rec]
+    assert n_inter > 0 and n_skip > 0
