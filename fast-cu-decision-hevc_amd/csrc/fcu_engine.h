@@ -34,14 +34,41 @@
 #define FCU_NOINLINE
 #define FCU_INLINE
 #define FCU_TABLE static const
-#define FCU_FOR_LANES for (int lane = 0; lane < 64; ++lane)
+/* The emulator runs the 64 lanes of a phase one after the other.  FCU_UNI(x) claims "x is the same in every lane":
+ * on the device it is a readfirstlane that silently takes lane 0's value, so a false claim corrupts the other lanes.
+ * The emulator checks the claim: inside a phase every lane that reaches the same FCU_UNI site must bring the value the
+ * first lane brought (tests/emu; the device build cannot check this). */
+static int g_emu_phase = 0, g_emu_in_phase = 0, g_emu_lane = 0, g_emu_relax = 0;
+/* a lane-private serial walk whose calls are data dependent per lane (the lanes that do call are in lockstep on the
+ * device, but the emulator cannot line their calls up): the check is suspended inside */
+#define FCU_EMU_RELAX(on) (g_emu_relax = (on))
+static inline int fcu_emu_phase_begin() { g_emu_phase++; g_emu_in_phase = 1; g_emu_lane = 0; return 0; }
+static inline int fcu_emu_phase_next(int lane) { if (lane + 1 >= 64) g_emu_in_phase = 0; g_emu_lane = lane + 1; return lane + 1; }
+/* the k-th visit of a site by a lane must bring what the k-th visit by the first visiting lane brought (lanes run in
+ * lockstep on the device; a lane may visit a site more often than the first one did: different trip counts) */
+template <class T> static inline T fcu_emu_uni(T v, int site, int line)
+{
+  enum { SITES = 2048, K = 32, B = 16 };
+  struct Seen { int phase, first, cur, idx, n; unsigned char vals[K][B]; };
+  static Seen seen[SITES];
+  if (g_emu_in_phase && !g_emu_relax && sizeof(T) <= B && site < SITES) {
+    Seen &s = seen[site];
+    if (s.phase != g_emu_phase) { s.phase = g_emu_phase; s.first = s.cur = g_emu_lane; s.idx = 0; s.n = 0; }
+    if (s.cur != g_emu_lane) { s.cur = g_emu_lane; s.idx = 0; }
+    if (g_emu_lane == s.first) { if (s.n < K) memcpy(s.vals[s.n++], &v, sizeof(T)); }
+    else if (s.idx < s.n && memcmp(s.vals[s.idx], &v, sizeof(T)) != 0) { fprintf(stderr, "FCU_UNI at line %d: value differs between lanes of one phase\n", line); abort(); }
+    s.idx++;
+  }
+  return v;
+}
+#define FCU_FOR_LANES for (int lane = fcu_emu_phase_begin(); lane < 64; lane = fcu_emu_phase_next(lane))
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
 #define FCU_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
 /* wave reductions of per-lane partial results into one LDS word (all 64 lanes call them, outside divergent code) */
 #define FCU_WAVE_ADD(p, v) (*(p) += (v))
 #define FCU_WAVE_MIN64(p, v) do { if ((v) < *(p)) *(p) = (v); } while (0)
 #define FCU_IN_LDS(p) do { } while (0)
-#define FCU_UNI(x) (x)
+#define FCU_UNI(x) fcu_emu_uni((x), __COUNTER__, __LINE__)
 #define FCU_HBM
 #define FCU_FLOOR(x) floor(x)
 #define FCU_CHECK(c) do { if (!(c)) { fprintf(stderr, "FCU_CHECK failed: %s (line %d)\n", #c, __LINE__); abort(); } } while (0)
@@ -81,6 +108,7 @@ template <class T> __device__ inline T fcu_uni(T v)
   return v;
 }
 #define FCU_UNI(x) fcu_uni(x)
+#define FCU_EMU_RELAX(on) do { } while (0)
 /* pointer-to-HBM type qualifier: accesses become global_ instead of flat_ instructions, which (unlike flat) may stay
  * in flight across a partial s_waitcnt -- needed for the one-ahead loads of the serial coefficient loops */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2207,6 +2235,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(int c, const CuObj *cu, int m, in
   const Env E = env_get(); cu = FCU_UNI(cu);
   FCU_IN_LDS(absbuf);
   const ChromaModeBuf *B = &E.G->cm[m];
+  FCU_EMU_RELAX(1);
   cab_reset_bits(c);
   code_intra_dir_chroma(c, mode);
   /* the five lanes (modes) walk the same luma TU tree in lockstep: they share the LDS walker stack (same values) */
@@ -2238,6 +2267,7 @@ FCU_DEV FCU_NOINLINE uint32_t chroma_tree_bits(int c, const CuObj *cu, int m, in
       { TU ch; tu_child(ch, st[sp], ci[sp], 0); ci[sp]++; sp++; st[sp] = ch; ci[sp] = -1; }
     }
   }
+  FCU_EMU_RELAX(0);
   return cab_bits(c);
 }
 
@@ -2298,7 +2328,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
         const int b = (lane >> tss), m = b % 5, comp = comp0 + b / 5;
         const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
-        const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, comp, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
+        const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 1 /* Cb and Cr share every parameter the call reads; the argument is wave-uniform */, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
         g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
         g_S.vc_dist[lane] = 0;
       }

@@ -589,14 +589,18 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       }
     }
   }
-  FCU_FOR_LANES {                                            /* RDOQ: one variant per lane, all priced against the snapshot */
-    if (lane < 6 && vok(lane)) {
-      const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane);
-      const int cbfCtx = (comp == 0 && trMode == 0) ? EST_ROOT_CBF : qt_cbf_ctx(tu, comp);      /* blockRootCbpBits, TComTrQuant.cpp:2358 */
-      const RdoqOut r = rdoq<0, 1>(CAB_GOON, G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp, 0, cbfCtx, P, G->r_rec + o, G->r_cg + lane * 64);
-      g_S.iv_abs[lane] = r.abs_sum; g_S.iv_lsp[lane] = r.last;
+  /* RDOQ: one variant per lane, all priced against the snapshot.  rdoq() and code_coeff_nxn() take block size and
+   * channel type as wave-uniform (scalar) arguments, so the luma variants and the chroma variants go in two rounds */
+  for (int ch = 0; ch < (NC ? 2 : 1); ch++) {
+    FCU_FOR_LANES {
+      if (lane < 6 && vok(lane) && ((lane >> 1) != 0) == (ch != 0)) {
+        const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane);
+        const int cbfCtx = (comp == 0 && trMode == 0) ? EST_ROOT_CBF : qt_cbf_ctx(tu, comp);      /* blockRootCbpBits, TComTrQuant.cpp:2358 */
+        const RdoqOut r = rdoq<0, 1>(CAB_GOON, G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp ? 1 : 0, 0, cbfCtx, P, G->r_rec + o, G->r_cg + lane * 64);   /* Cb and Cr share every parameter the call reads */
+        g_S.iv_abs[lane] = r.abs_sum; g_S.iv_lsp[lane] = r.last;
+      }
+      if (lane == 0 && ch == 0) E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0));
     }
-    if (lane == 0) E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0));
   }
   FCU_FOR_LANES {                                            /* dequantisation (transposed for the inverse stages) */
     for (int v = 0; v < 6; v++) {
@@ -632,13 +636,15 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       FCU_WAVE_ADD(&g_S.acc[v], sse);
     }
   }
-  FCU_FOR_LANES {                                            /* bits of (cbf, coefficients) per variant on lane-private coders */
-    if (lane < 6 && vok(lane) && g_S.iv_abs[lane] > 0) {
-      const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane), c = CAB_LANE0 + lane;
-      cab_copy1(&g_S.cab[c], &g_S.cab[CAB_GOON]); cab_reset_bits(c);
-      cab_bin(c, 1, qt_cbf_ctx(tu, comp));
-      code_coeff_nxn<0>(c, G->p_qscan + o, 1, g_S.iv_lsp[lane], l2, comp, 0, lane & 1, P, g_S.lane_abs[lane]);
-      g_S.iv_bits[lane] = cab_bits(c);
+  for (int ch = 0; ch < (NC ? 2 : 1); ch++) {                  /* bits of (cbf, coefficients) per variant on lane-private coders */
+    FCU_FOR_LANES {
+      if (lane < 6 && vok(lane) && ((lane >> 1) != 0) == (ch != 0) && g_S.iv_abs[lane] > 0) {
+        const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane), c = CAB_LANE0 + lane;
+        cab_copy1(&g_S.cab[c], &g_S.cab[CAB_GOON]); cab_reset_bits(c);
+        cab_bin(c, 1, qt_cbf_ctx(tu, comp));
+        code_coeff_nxn<0>(c, G->p_qscan + o, 1, g_S.iv_lsp[lane], l2, comp ? 1 : 0, 0, lane & 1, P, g_S.lane_abs[lane]);
+        g_S.iv_bits[lane] = cab_bits(c);
+      }
     }
   }
   FCU_SERIAL {                                               /* per component: coded / skipped / transform-skip (TEncSearch.cpp:4640-4900) */
