@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- CTUs/sec of the CU depth/mode RDO decision (TEncCu::compressCtu equivalent).
 
-Workload (BASELINE.json configs[2]): 3840x2160 all-intra, QP {22,27,32,37}, full depth-0..3
-quadtree + chroma RDO, synthetic "textured" YUV, resident in HBM before the
-timed region.  A chain = (frame, QP) = one I slice, the unit HM decides strictly serially;
-`--frames` frames x 4 QPs chains are in flight per GPU, one wavefront each; by default that is twice the number of
-wave slots of the device, ordered longest (lowest QP) first, so that the slots the short high-QP chains free early are
-refilled by the hardware dispatcher.  A *step* advances every chain by `--ctus-per-step` CTUs (compressCtu + encodeCtu
-replay per CTU) in one launch.
+Default workload (BASELINE.json configs[2]): 3840x2160 all-intra, QP {22,27,32,37}, full depth-0..3 quadtree + chroma RDO,
+synthetic "textured" YUV, resident in HBM before the timed region.  A chain = one slice of one (frame, QP)
+= the unit HM decides strictly serially.  Slices are HM's SliceMode 1 with `--slice-ctus` CTUs (default 120 = two CTU rows:
+17 slices per 4K frame, the last one holding the partial bottom row), so the timed region walks CTUs without above
+neighbours (first row of a slice), CTUs with above / above-right neighbours (second row) and the 48-sample-high bottom
+row, and every chain is walked to the end of its slice.  A *step* advances every chain by `--ctus-per-step` CTUs
+(compressCtu + encodeCtu replay per CTU) in one launch; chains are ordered longest (lowest QP) first.
+
+`--config ldp` (BASELINE.json configs[4]): 3840x2160 lowdelay_P, QP 32: picture 0 (intra) of every clip is decided,
+deblocked and padded untimed; the timed steps decide P-picture CTUs (merge / AMVP / full-search integer ME +-SearchRange
+with sub-sample refinement / inter RQT / intra fallback) against that reference.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; every rank
-   owns its own frames -- no collective on the data path; weak scaling)
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; every rank owns its own frames /
+   clips -- no collective on the data path; weak scaling.  `--shard slices`: ONE set of frames whose slice chains are split
+   over the ranks (sharding.slices_for_rank), outputs gathered on rank 0 after the timed region; strong scaling.)
 
-Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline" + transfer / chain-count / split-match detail).
 """
 import argparse
 import json
@@ -25,68 +30,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 1024 + rec 12288 + coeff 24576 + meta 5120
+ALGO_BYTES_PER_CTU_LDP = 55300 + 3 * 4096 * 3 // 2   # + the reference samples of the three part-size searches' windows' core (one 64x64 4:2:0 block each)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
-def measured_traffic(chains, ctus_per_step):
-    """HBM-side bytes per launch of the engine kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when the summary is for another workload shape."""
+def measured_traffic(config, chains, ctus_per_step):
+    """HBM-side bytes per launch of the engine kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and the
+    commit the profiled library was built from.  None when the summary is for another workload shape."""
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
-        if d.get("chains_per_launch") != chains or d.get("ctus_per_chain_per_launch") != ctus_per_step:
-            return None
-        return float(d["traffic_bytes_per_launch"])
+        if d.get("config") != config or d.get("chains_per_launch") != chains or d.get("ctus_per_chain_per_launch") != ctus_per_step:
+            return None, None
+        return float(d["traffic_bytes_per_launch"]), d.get("commit")
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
-def gen_textured_gpu(torch, dev, w, h, seed):
-    """The SURVEY 8d 'textured' generator evaluated on the device (torch RNG)."""
+def gen_textured_gpu(torch, dev, w, h, seed, shift=(0, 0)):
+    """The SURVEY 8d 'textured' generator evaluated on the device (torch RNG); `shift` moves the deterministic part
+    (lowdelay_P clips: global motion of (3, 1) samples per picture) while the noise is drawn afresh per call."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
-    x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
+    y = torch.arange(h, device=dev, dtype=torch.float32)[:, None] + shift[1]
+    x = torch.arange(w, device=dev, dtype=torch.float32)[None, :] + shift[0]
     noise = torch.randn((h, w), generator=g, device=dev) * 18 * (1 + ((x // 64 + y // 64) % 3)) / 2
     Y = 128 + 50 * torch.sin(x / 9 + y / 31) + 35 * torch.cos(y / 7) * torch.sin(x / 53) + noise
-    cy = torch.arange(h // 2, device=dev, dtype=torch.float32)[:, None]
-    cx = torch.arange(w // 2, device=dev, dtype=torch.float32)[None, :]
+    cy = torch.arange(h // 2, device=dev, dtype=torch.float32)[:, None] + shift[1] / 2
+    cx = torch.arange(w // 2, device=dev, dtype=torch.float32)[None, :] + shift[0] / 2
     U = 128 + 25 * torch.sin(cx / 23) + torch.randn((h // 2, w // 2), generator=g, device=dev) * 5 + 0 * cy
     V = 128 + 25 * torch.cos(cy / 19) + torch.randn((h // 2, w // 2), generator=g, device=dev) * 5 + 0 * cx
     f = lambda a: a.round().clamp(0, 255).to(torch.uint8).contiguous()
     return f(Y), f(U), f(V)
 
 
-def cpu_baseline(frame_np, qp, budget_s=15.0, gpu_ctus=()):
-    """The oracle (plain-C restatement of the reference loop) on this box's host cores, 1 thread,
-    on the first CTUs of the same workload.  A reported baseline, not the target.  As the checker it also compares the
-    CU split decisions (depth per 4x4 partition, and the NxN flag of 8x8 CUs) the GPU published for the first CTUs of
-    the same chain -- the second half of BASELINE's metric."""
-    import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import hmo_py
-    enc = hmo_py.Encoder(*frame_np, qp)
+def gen_moving_gpu(torch, dev, w, h, seed, poc):
+    """picture `poc` of a lowdelay_P clip: one smooth-noise texture (seeded per clip) moving by (3, 1) samples per picture
+    plus fresh +-2 noise -- the same recipe as tests/search_trace.py:moving_frame, on the device"""
+    Y, U, V = gen_textured_gpu(torch, dev, w + 32, h + 32, seed)
+    dx, dy = (3 * poc) % 32, poc % 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(100000 + 17 * seed + poc)
+    n = torch.randint(-2, 3, (h, w), generator=g, device=dev, dtype=torch.int16)
+    Yc = (Y[dy:dy + h, dx:dx + w].to(torch.int16) + n).clamp(0, 255).to(torch.uint8).contiguous()
+    return Yc, U[dy // 2:dy // 2 + h // 2, dx // 2:dx // 2 + w // 2].contiguous(), V[dy // 2:dy // 2 + h // 2, dx // 2:dx // 2 + w // 2].contiguous()
+
+
+def split_match(want, got):
+    return int(((want["depth"] == got["depth"]) & (want["part_size"] == got["part_size"]) & (want["pred_mode"] == got["pred_mode"])).sum()), want["depth"].size
+
+
+def cpu_leg(make_encoder, first_ctu, gpu_lookup, budget_s, label):
+    """The oracle (plain-C restatement of the reference loop, pinned candidate by candidate by the reference's own search
+    code -- oracle/README.md) on this box's host cores, 1 thread, on the first CTUs of a chain of the same workload.  A
+    reported baseline, not the target.  As the checker it compares the CU split decisions (depth, part size and prediction
+    mode per 4x4 partition) the GPU published for the same CTUs -- the second half of BASELINE's metric."""
+    enc = make_encoder()
     t0 = time.time()
-    n = 0
-    while n < enc.n_ctu and (time.time() - t0) < budget_s:
-        enc.compress_ctu(n)
+    n = same = total = 0
+    while first_ctu + n < enc.n_ctu and (time.time() - t0) < budget_s:
+        a = first_ctu + n
+        enc.compress_ctu(a)
+        got = gpu_lookup(a)
+        if got is not None:
+            s, t = split_match(enc.ctu_arrays(a), got)
+            same += s
+            total += t
         n += 1
     dt = time.time() - t0
-    same = total = 0
-    for a, got in enumerate(gpu_ctus):
-        if a >= n:
-            break
-        want = enc.ctu_arrays(a)
-        same += int(((want["depth"] == got["depth"]) & (want["part_size"] == got["part_size"])).sum())
-        total += want["depth"].size
-    res = {"value": n / dt, "unit": "CTUs/sec", "cores": 1, "kind": "port",
-           "sample": f"first {n} CTUs of frame 0 (3840x2160, QP{qp}), oracle/libhmo.so single thread, {dt:.1f}s"}
-    match = {"ctus": min(n, len(gpu_ctus)), "partitions_equal": same, "partitions": total,
-             "frac": (same / total) if total else None,
-             "what": f"depth + part_size per 4x4 partition, GPU chain (frame 0, QP{qp}) vs the oracle on the same CTUs"}
-    return res, match
+    return n, dt, same, total, label
 
 
 def main():
@@ -94,22 +108,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["intra", "ldp"], default="intra")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames", type=int, default=2048, help="frames per GPU (x4 QPs = chains per GPU)")
-    ap.add_argument("--ctus-per-step", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=0, help="frames (intra) / clips (ldp) per GPU; 0 = 120 (intra: x4 QPs x17 slices = 8160 chains) / 240 (ldp: x17 slices = 4080 chains)")
+    ap.add_argument("--slice-ctus", type=int, default=120, help="HM SliceMode 1 / SliceArgument: CTUs per slice = per chain (0: one slice per frame)")
+    ap.add_argument("--ctus-per-step", type=int, default=0, help="0 = walk the whole slice over warmup + steps launches (intra) / 2 (ldp)")
     ap.add_argument("--qps", default="22,27,32,37")
+    ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--order", choices=["frame", "qp"], default="qp",
-                    help="chain order inside a launch: frame-major or (default) QP-major, lowest QP = longest chains first; "
-                         "with more chains than wave slots the hardware dispatcher then backfills the slots freed by the "
-                         "short high-QP chains")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep and the transfer measurement")
+    ap.add_argument("--shard", choices=["frames", "slices"], default="frames")
     ap.add_argument("--state", choices=["training", "testing"], default="training",
-                    help="fork state of the timed steps.  training (default, the headline metric): exhaustive RDO.  "
-                         "testing: the fork's Naive pruning; the OBF maps come from the device pre-pass, the first warm-up "
-                         "step runs in the Verifying state and its counters set the per-depth switches (SetDecisionSwitch)")
+                    help="fork state of the timed steps (intra).  training (default, the headline metric): exhaustive RDO.  testing: "
+                         "the fork's Naive pruning; OBF maps from the device pre-pass, the first warm-up step runs in the Verifying "
+                         "state and its counters set the per-depth switches (SetDecisionSwitch)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()
@@ -119,8 +135,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # FCU_BENCH_REHEARSAL=1 (never set by the driver): rehearse the N>1 code path on a one-GPU box -- all ranks share
-    # cuda:0 and rendezvous over gloo, since RCCL refuses two ranks on one device.  The reported number is then not a
-    # scaling measurement and says so in `config`.
+    # cuda:0 and rendezvous over gloo, since RCCL refuses two ranks on one device.  Not a scaling measurement; says so.
     rehearsal = os.environ.get("FCU_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
@@ -132,49 +147,85 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    qps = [int(q) for q in args.qps.split(",")]
+    ldp = args.config == "ldp"
     W, H = args.width, args.height
-    n_chains = args.frames * len(qps)
-    total_ctus_chain = (args.warmup + args.steps) * args.ctus_per_step
+    n_ctu = ((W + 63) // 64) * ((H + 63) // 64)
+    sl = args.slice_ctus if args.slice_ctus > 0 else n_ctu
+    n_sl = (n_ctu + sl - 1) // sl
+    qps = [32] if ldp else [int(q) for q in args.qps.split(",")]
+    n_frames = args.frames or (240 if ldp else 120)
+    cps = args.ctus_per_step or (2 if ldp else max(1, sl // (args.warmup + args.steps)))
+    walked = (args.warmup + args.steps) * cps
+    assert walked <= sl, "bench walks past the end of the slice"
+    strong = args.shard == "slices" and world > 1
+    # chains: (frame seed, qp, slice).  weak scaling: every rank owns its own frames; --shard slices: all ranks see the same
+    # frames and each owns whole slices of them (no slice is shared, no collective on the data path)
+    seeds = [s for s, _ in pkg.sharding.chains_for_rank(n_frames, [0], 0 if strong else rank)]
+    owner_of = lambda k: 0
+    if strong:
+        owned = {first // sl: r for r in range(world) for first, _ in pkg.sharding.slices_for_rank(n_ctu, sl, world, r)}
+        owner_of = lambda k: owned[k]
+    my_slices = [k for k in range(n_sl) if not strong or owner_of(k) == rank]
+    chain_list = sorted(((seed, qp, k) for seed in seeds for qp in qps for k in my_slices), key=lambda c: (c[1], c[0], c[2]))
+    n_chains = len(chain_list)
     eng = pkg.CuEngine(W, H, max_chains=n_chains, device=local)
-    assert total_ctus_chain <= eng.n_ctu, "bench walks past the end of the frame"
-    # inputs resident in HBM before timing; every chain gets its own reconstruction plane set,
-    # the 4 QP chains of a frame share its source planes
-    out_bytes = pkg.engine.CTU_OUT_BYTES * total_ctus_chain
-    frames, cache = [], {}
-    chain_list = pkg.sharding.chains_for_rank(args.frames, qps, rank)
-    if args.order == "qp":
-        chain_list = sorted(chain_list, key=lambda c: (c[1], c[0]))
-    seed_index = {}
-    for ci, (seed, qp) in enumerate(chain_list):
-        if seed not in cache:
-            cache[seed] = gen_textured_gpu(torch, dev, W, H, seed=seed)
-            seed_index[seed] = len(frames)
-            frames.append(cache[seed])
-        fr = cache[seed]
-        rec = [torch.zeros_like(p) for p in fr]
-        out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
-        eng.init_chain(ci, fr, qp=qp, rec=rec, out=out)
+    nb = pkg.engine.CTU_OUT_BYTES
+
+    frames, recs, outs, refs, fps = {}, {}, {}, {}, {}
+    for seed in seeds:
+        frames[seed] = gen_moving_gpu(torch, dev, W, H, seed, 1 if ldp else 0) if ldp else gen_textured_gpu(torch, dev, W, H, seed)
+    for seed in seeds:
+        for qp in qps:
+            recs[(seed, qp)] = [torch.zeros_like(p) for p in frames[seed]]
+            outs[(seed, qp)] = torch.zeros(nb * n_ctu, dtype=torch.uint8, device=dev)
+
+    if ldp:
+        # untimed: picture 0 of every clip (intra, same slice structure), loop filter, padding -> the reference pictures
+        fp0 = pkg.engine.ldp_slice(32, 0)
+        pic0 = {seed: gen_moving_gpu(torch, dev, W, H, seed, 0) for seed in seeds}
+        for ci, (seed, qp, k) in enumerate(chain_list):
+            eng.init_chain(ci, pic0[seed], fp0.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp0)
+            if n_sl > 1:
+                eng.set_range(ci, k * sl, min(sl, n_ctu - k * sl))
+        eng.compress_chains(0, n_chains, sl)
+        for seed in seeds:
+            eng.deblock(out=outs[(seed, 32)], rec=recs[(seed, 32)])
+            refs[seed] = eng.pad_reference(recs[(seed, 32)])
+            recs[(seed, 32)] = [torch.zeros_like(p) for p in frames[seed]]
+        eng.sync()
+        pic0_host = [p.cpu().numpy() for p in pic0[seeds[0]]] if rank == 0 else None
+        del pic0
+        fp1 = pkg.engine.ldp_slice(32, 1)
+        fp1.search_range = args.search_range
+
+    def bind(ci):
+        seed, qp, k = chain_list[ci]
+        if ldp:
+            eng.init_chain(ci, frames[seed], fp1.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp1, ref=refs[seed])
+        else:
+            eng.init_chain(ci, frames[seed], qp=qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)])
+        if n_sl > 1:
+            eng.set_range(ci, k * sl, min(sl, n_ctu - k * sl))
+
+    for ci in range(n_chains):
+        bind(ci)
     torch.cuda.synchronize()
 
     def step():
-        eng.compress_chains(0, n_chains, args.ctus_per_step)
+        eng.compress_chains(0, n_chains, cps)
 
     switches = None
-    if args.state == "testing":
-        # untimed: OBF pre-pass of every frame, one Verifying step, switches from its counters, then Testing
+    if args.state == "testing" and not ldp:
         assert args.warmup >= 1, "--state testing uses the first warm-up step as the Verifying step"
-        obf = [eng.obf_prepass(fr[0])[0][0].contiguous() for fr in frames]
-        chain_obf = [obf[seed_index[seed]] for seed, _ in chain_list]
-        for ci in range(n_chains):
-            eng.set_decision(ci, pkg.engine.VERIFYING, chain_obf[ci])
+        obf = {seed: eng.obf_prepass(frames[seed][0])[0][0].contiguous() for seed in seeds}
+        for ci, (seed, qp, k) in enumerate(chain_list):
+            eng.set_decision(ci, pkg.engine.VERIFYING, obf[seed])
         step()
         ver = eng.verify_counts(0, n_chains)
         switches = pkg.engine.decision_switch(ver)
-        for ci in range(n_chains):
-            eng.set_decision(ci, pkg.engine.TESTING, chain_obf[ci], *switches)
-    for _ in range(args.warmup - (1 if args.state == "testing" else 0)):
+        for ci, (seed, qp, k) in enumerate(chain_list):
+            eng.set_decision(ci, pkg.engine.TESTING, obf[seed], *switches)
+    for _ in range(args.warmup - (1 if switches is not None else 0)):
         step()
     eng.sync()
     eng.kernel_ms()                       # drop warm-up launches from the event accumulator
@@ -191,42 +242,139 @@ def main():
     dt = pkg.sharding.reduce_step_time(dist, time.perf_counter() - t0, None if rehearsal else dev)
     kernel_ms, launches = eng.kernel_ms()
 
-    ctus_per_step_gpu = n_chains * args.ctus_per_step
-    total = ctus_per_step_gpu * args.steps * world
+    # chains at the end of a frame have fewer CTUs left than cps: count what was really decided in the timed steps
+    timed_ctus_gpu = 0
+    for seed, qp, k in chain_list:
+        n_in_slice = min(sl, n_ctu - k * sl)
+        timed_ctus_gpu += max(0, min(n_in_slice, walked) - min(n_in_slice, args.warmup * cps))
+    if dist is not None:
+        t = torch.tensor([timed_ctus_gpu], dtype=torch.float64, device=None if rehearsal else dev)
+        dist.all_reduce(t)
+        total = int(t.item())
+    else:
+        total = timed_ctus_gpu
     value = total / dt
+
+    if strong:                             # after the timed region: the other ranks' slices of every frame reach rank 0
+        for key in sorted(outs):
+            v = outs[key].view(n_ctu, nb)
+            for k in range(n_sl):
+                owner = owner_of(k)
+                a, b = k * sl, min(n_ctu, (k + 1) * sl)
+                buf = v[a:b].contiguous() if not rehearsal else v[a:b].cpu().contiguous()
+                dist.broadcast(buf, src=owner)
+                if rank == 0 and owner != 0:
+                    v[a:b] = buf.to(dev)
+
     if rank == 0:
-        achieved = (ALGO_BYTES_PER_CTU * ctus_per_step_gpu) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        per_launch = timed_ctus_gpu / max(1, args.steps)
+        algo = ALGO_BYTES_PER_CTU_LDP if ldp else ALGO_BYTES_PER_CTU
+        achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
+        what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
+                f"merge + AMVP + full search +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
+                f"one reference picture, TMVP off, AMP off" if ldp else
+                f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO (BASELINE configs[2])")
         res = {
-            "metric": "CTUs/sec (RDO decision only) at 4K all-intra", "value": value, "unit": "CTUs/sec",
+            "metric": "CTUs/sec (RDO decision only) at 4K " + ("lowdelay_P" if ldp else "all-intra"), "value": value, "unit": "CTUs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int32+f64",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO "
-                                   f"(BASELINE configs[2]); {args.frames} frames x {len(qps)} QPs = {n_chains} chains/GPU, "
-                                   f"{args.ctus_per_step} CTU/chain/step, {args.order}-major order",
-                       "chains_per_gpu": n_chains, "ctus_per_step": ctus_per_step_gpu * world,
+            "config": {"workload": what + f"; {len(seeds)} {'clips' if ldp else 'frames'} x {len(qps)} QP x {len(my_slices)} slices of {sl} CTUs (HM SliceMode 1) = {n_chains} chains/GPU, "
+                                          f"{cps} CTUs/chain/step, lowest QP first",
+                       "chains_per_gpu": n_chains, "ctus_per_step": int(per_launch) * (1 if strong else world),
+                       "timed_ctu_range": f"CTUs {args.warmup * cps}..{walked - 1} of every {sl}-CTU slice: first-row CTUs (no above neighbour), second-row CTUs "
+                                          f"(above / above-right neighbours) and, in the last slice of a frame, the partial bottom CTU row",
                        **({"rehearsal": "all ranks on one GPU over gloo: not a scaling measurement"} if rehearsal else {}),
+                       **({"shard": "slices of the same frames over the ranks; outputs gathered on rank 0 after the timed region"} if strong else {}),
                        "state": args.state if switches is None else
                        f"testing (Naive switches skip2Nx2N={switches[0].tolist()} terminate={switches[1].tolist()} from a Verifying step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(n_chains, args.ctus_per_step) if switches is None else None,
-                         "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profile_commit": prof_commit,
+                         "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches,
+                         "note": "the kernel is latency / issue bound (serial CABAC + RDOQ per chain), not HBM bound: see DESIGN.md 3"},
         }
-        if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N=1 only
-            fr0 = [p.cpu().numpy() for p in frames[0]]
-            gpu_ctus = []
-            seed0 = chain_list[0][0]                      # frames[0]: the lowest seed in either chain order
-            if args.state == "training" and (seed0, 32) in chain_list:
-                c32 = chain_list.index((seed0, 32))
-                gpu_ctus = [eng.ctu_out(c32, a) for a in range(total_ctus_chain)]
-            res["cpu_baseline"], res["split_flag_match"] = cpu_baseline(fr0, 32, gpu_ctus=gpu_ctus)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        if world == 1 and not args.no_cpu_baseline:
+            import hmo_py
+            qp_list = [32] if ldp else qps
+            legs = []
+            for qp in qp_list:
+                ci = chain_list.index((seeds[0], qp, 0))
+                fr = [p.cpu().numpy() for p in frames[seeds[0]]]
+                if ldp:
+                    _, q1, lam = hmo_py.ldp_slice(1, 32)
+                    mk = lambda fr=fr: hmo_py.Encoder(*fr, q1, slice_ctus=sl if n_sl > 1 else 0, ref=[p.cpu().numpy() for p in _unpad(refs[seeds[0]], W, H)],
+                                                      lambda_override=lam, search_range=args.search_range)
+                else:
+                    mk = lambda fr=fr, qp=qp: hmo_py.Encoder(*fr, qp, slice_ctus=sl if n_sl > 1 else 0)
+                look = lambda a, ci=ci: eng.ctu_out(ci, a) if a < walked and switches is None else None
+                legs.append(cpu_leg(mk, 0, look, 15.0 if qp == 32 else 1.5, f"QP{qp}"))
+            n32, dt32 = [(n, d) for n, d, _, _, lab in legs if lab == "QP32"][0]
+            res["cpu_baseline"] = {"value": n32 / dt32, "unit": "CTUs/sec", "cores": 1, "kind": "port",
+                                   "sample": f"first {n32} CTUs of slice 0 of {'clip' if ldp else 'frame'} 0 ({W}x{H}, QP32{', P picture' if ldp else ''}), oracle/libhmo.so single thread, {dt32:.1f}s"}
+            same, tot = sum(l[2] for l in legs), sum(l[3] for l in legs)
+            res["split_flag_match"] = {"partitions_equal": same, "partitions": tot, "frac": (same / tot) if tot else None,
+                                       "chains": [f"{lab}: {n} CTUs" for n, _, _, _, lab in legs],
+                                       "what": "depth + part size + prediction mode per 4x4 partition, one GPU chain per QP vs the in-repo oracle on the same CTUs; "
+                                               "the oracle's PU/TU search loops are pinned by the reference's own TEncSearch.cpp, its CU-level glue (xCompressCU) is restated"}
         else:
             res["cpu_baseline"] = None
+        if world == 1 and not args.no_sweep:
+            # (b) transfers the metric's definition puts next to the decision: source planes in, fcu_ctu_out out (pinned host memory)
+            nf = min(8, len(seeds))
+            host = [torch.empty((nf,) + tuple(p.shape), dtype=torch.uint8).pin_memory() for p in frames[seeds[0]]]
+            devb = [torch.empty((nf,) + tuple(p.shape), dtype=torch.uint8, device=dev) for p in frames[seeds[0]]]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for hb, db in zip(host, devb):
+                db.copy_(hb, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d_s = time.perf_counter() - t1
+            src_bytes = sum(hb.numel() for hb in host)
+            ob = outs[(seeds[0], qps[0])]
+            hout = torch.empty(ob.shape, dtype=torch.uint8).pin_memory()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hout.copy_(ob, non_blocking=True)
+            torch.cuda.synchronize()
+            d2h_s = time.perf_counter() - t1
+            h2d_gbps, d2h_gbps = src_bytes / h2d_s / 1e9, ob.numel() / d2h_s / 1e9
+            # per decided CTU: its share of the source planes (once per frame, shared by the QP chains) + its fcu_ctu_out
+            per_ctu_in = (W * H * 3 // 2) / n_ctu / (1 if ldp else len(qps))
+            xfer_s = total * (per_ctu_in / (h2d_gbps * 1e9) + nb / (d2h_gbps * 1e9))
+            res["transfers"] = {"h2d_GBps": h2d_gbps, "d2h_GBps": d2h_gbps, "source_bytes_per_ctu": per_ctu_in, "ctu_out_bytes": nb,
+                                "seconds_for_timed_ctus": xfer_s, "value_incl_transfers": total / (dt + xfer_s),
+                                "note": "pinned host memory, measured after the timed region; `value` is with inputs resident in HBM"}
+            # (c) throughput against the number of chains in flight (SURVEY 8d config 3 asks for >= 16 frames: 64 chains = 16 frames x 4 QPs)
+            sweep = {}
+            k = 2 if ldp else 4
+            for n in (64, 256, 1024, 4096, n_chains):
+                if n > n_chains or str(n) in sweep:
+                    continue
+                for ci in range(n):
+                    bind(ci)
+                eng.sync()
+                t1 = time.perf_counter()
+                eng.compress_chains(0, n, k)
+                eng.sync()
+                sweep[str(n)] = n * k / (time.perf_counter() - t1)
+            res["chains_sweep"] = {"ctus_per_sec": sweep, "ctus_per_chain": k,
+                                   "note": "first CTUs of the first n chains (lowest QP first), one launch each; one chain = one wavefront"}
         print(json.dumps(res), flush=True)
     eng.destroy()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _unpad(padded, w, h):
+    """padded reference planes (engine.pad_reference) -> the picture planes"""
+    out = []
+    for k, t in enumerate(padded):
+        m = 80 >> (1 if k else 0)
+        pw, ph = (w >> (1 if k else 0)) + 2 * m, (h >> (1 if k else 0)) + 2 * m
+        out.append(t.view(ph, pw)[m:ph - m, m:pw - m])
+    return out
 
 
 if __name__ == "__main__":

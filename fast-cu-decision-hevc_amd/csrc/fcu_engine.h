@@ -1426,6 +1426,7 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                       
           const int log2 = 6 - cu->depth[part] - cu->tr_idx[part], np = 1 << (2 * (log2 - 2)), tp = part & ~(np - 1);
           const int st = cu->pred_mode[part] == MODE_INTRA ? coef_scan_idx(cu->intra_dir[0][tp], log2, 0) : 0;   /* inter: SCAN_DIAG */
           v = cu->coef[0][tp * 16 + k_iscan[k_scan_off[st * 4 + log2 - 2] + (i - tp * 16)]];
+          if (cu->pred_mode[part] == MODE_INTER && !cu->cbf[0][part]) v = 0;   /* dropped residual: the levels of an earlier candidate are still there */
         }
         p->coeff_y[i] = v;
       }
@@ -1437,6 +1438,7 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                       
           const int mode = chroma_final_mode(cu, tp), o = k_scan_off[(cu->pred_mode[part] == MODE_INTRA ? coef_scan_idx(mode, log2, 1) : 0) * 4 + log2 - 2];
           const int sp = k_iscan[o + (i - tp * 4)];
           vb = cu->coef[1][tp * 4 + sp]; vr = cu->coef[2][tp * 4 + sp];
+          if (cu->pred_mode[part] == MODE_INTER) { if (!cu->cbf[1][part]) vb = 0; if (!cu->cbf[2][part]) vr = 0; }
         }
         p->coeff_cb[i] = vb; p->coeff_cr[i] = vr;
       }

@@ -169,6 +169,14 @@ void    hmo_deblock(HmoEnc *e, int betaOffsetDiv2, int tcOffsetDiv2);
 void    hmo_deblock_pic(const HmoCtu *pic, int width, int height, uint8_t *recY, uint8_t *recU, uint8_t *recV,
                         int betaOffsetDiv2, int tcOffsetDiv2);
 
+/* sample adaptive offset (TEncSampleAdaptiveOffset::SAOProcess, TEncSampleAdaptiveOffset.cpp:257; TEncGOP.cpp:1434), hmo_sao.c */
+typedef struct { int mode, type, aux; int offset[32]; } HmoSaoOffset;      /* mode 0 off / 1 new / 2 merge; type: EO 0..3, BO 4 (merge: 0 left, 1 above); aux: band position */
+typedef struct { HmoSaoOffset c[3]; } HmoSaoBlk;
+typedef struct { int64_t diff[5][32], count[5][32]; } HmoSaoStat;           /* [type][class]: EO classes at [edgeType + 2], BO bands at [band] */
+void    hmo_sao_stats(int width, int height, const uint8_t *const org[3], const uint8_t *const src[3], HmoSaoStat *stats);
+void    hmo_sao_picture(int width, int height, int slice_ctus, int qp, int slice_type, const double lambda[3], const int enabled[3],
+                        const uint8_t *const org[3], uint8_t *const rec[3], HmoSaoBlk *coded, HmoSaoStat *stats_out, int off_count[3]);
+
 /* fork states (CurrentState, globals_YS.h; getCurrentState, tools_YS.cpp:1237-1242) */
 #define HMO_TRAINING  0
 #define HMO_VERIFYING 1

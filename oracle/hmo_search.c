@@ -125,6 +125,15 @@ static void cu_copy_to_pic(HmoEnc *e, const HmoCU *cu)
   memcpy(p->coeff_y + off * 16, cu->coef[0], sizeof(int32_t) * (size_t)(n * 16));
   memcpy(p->coeff_cb + off * 4, cu->coef[1], sizeof(int32_t) * (size_t)(n * 4));
   memcpy(p->coeff_cr + off * 4, cu->coef[2], sizeof(int32_t) * (size_t)(n * 4));
+  /* An inter CU whose residual was dropped (skip, or the root-cbf-zero choice of encodeResAndCalcRdInterCU,
+   * TEncSearch.cpp:4465-4478) keeps whatever an earlier candidate left in m_pcTrCoeff; HM never reads it (cbf 0).  The
+   * published CTU carries zeros there, so that the output does not depend on buffer history. */
+  for (int i = 0; i < n; i++) {
+    if (cu->pred_mode[i] != HMO_MODE_INTER) continue;
+    if (!cu->cbf[0][i]) memset(p->coeff_y + (off + i) * 16, 0, sizeof(int32_t) * 16);
+    if (!cu->cbf[1][i]) memset(p->coeff_cb + (off + i) * 4, 0, sizeof(int32_t) * 4);
+    if (!cu->cbf[2][i]) memset(p->coeff_cr + (off + i) * 4, 0, sizeof(int32_t) * 4);
+  }
 }
 
 /* neighbour field access: inside the working CU -> its arrays, else the committed picture

@@ -44,6 +44,7 @@
 #include "TLibEncoder/TEncBinCoderCABACCounter.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncSearch.h"
+#include "TLibEncoder/TEncSampleAdaptiveOffset.h"
 #undef private
 #undef protected
 #include <math.h>
@@ -570,6 +571,62 @@ int ref_merge_cu(int ctu, int zidx, int depth, int cand, int noResidual, RefCuOu
   read_cu(cu, depth, out);
   out->dist_luma = 0;
   return numValid;
+}
+
+/* ---- sample adaptive offset: the reference's own TEncSampleAdaptiveOffset on the picture held by the driver -------------
+ * PicYuvOrg / PicYuvRec (the deblocked picture) are loaded with ref_set_org / ref_set_rec.  The call sequence is TEncGOP's
+ * (TEncGOP.cpp:1427-1441): initRDOCabacCoder(go-on coder, slice) then SAOProcess(pic, sliceEnabled, slice lambdas, SaoCtuBoundary
+ * = false).  slice_ctus > 0 cuts the picture into slices of that many CTUs (SliceMode 1) the way TEncGOP / TEncSlice leave
+ * them in the TComPicSym: one TComSlice per slice, every CTU pointing at its own, LFCrossSliceBoundaryFlag 1.
+ * layer = pic->getSlice(0)->getDepth() (temporal layer of the GOP entry); disabledRate[comp] preloads
+ * m_saoDisabledRate[comp][layer - 1] (what earlier pictures would have left, :895-917).
+ * out_params[ctu][comp][0..34] = modeIdc, typeIdc, typeAuxInfo, offset[32]; out_stats[ctu][comp][type][0..63] = diff[32], count[32];
+ * out_misc[0..2] = sliceEnabled, out_rate[comp] = m_saoDisabledRate[comp][layer] afterwards. */
+int ref_sao(int sliceType, int qp, const double *lambdas, int slice_ctus, int layer, const double *disabledRate,
+            int *out_params, long long *out_stats, int *out_misc, double *out_rate)
+{
+  const int n = (int)g_pic->getNumberOfCtusInFrame();
+  g_slice->setSliceType(sliceType == 0 ? I_SLICE : P_SLICE); g_slice->setSliceQp(qp); g_slice->setDepth(layer);
+  g_slice->setLFCrossSliceBoundaryFlag(true);
+  g_slice->setLambdas(lambdas);
+  if (slice_ctus > 0) {
+    const int n_sl = (n + slice_ctus - 1) / slice_ctus;
+    for (int k = 1; k < n_sl; k++) {
+      g_pic->allocateNewSlice();
+      TComSlice *sl = g_pic->getSlice(k);
+      sl->copySliceInfo(g_slice);
+      sl->setSPS(g_slice->getSPS()); sl->setPPS(g_slice->getPPS()); sl->setPic(g_pic);
+      sl->setLFCrossSliceBoundaryFlag(true);
+    }
+    for (int k = 0; k < n_sl; k++) {
+      TComSlice *sl = g_pic->getSlice(k);
+      const int a = k * slice_ctus, b = std::min(n, a + slice_ctus);
+      sl->setSliceCurStartCtuTsAddr(a); sl->setSliceCurEndCtuTsAddr(b);
+      sl->setSliceSegmentCurStartCtuTsAddr(a); sl->setSliceSegmentCurEndCtuTsAddr(b);
+      for (int c = a; c < b; c++) g_pic->getCtu(c)->m_pcSlice = sl;
+    }
+  }
+  TEncSampleAdaptiveOffset *sao = new TEncSampleAdaptiveOffset();
+  sao->create(g_sps.getPicWidthInLumaSamples(), g_sps.getPicHeightInLumaSamples(), CHROMA_420, 64, 64, 4, 0, 0);   /* TEncTop.cpp:100-104: SaoLumaOffsetBitShift 0 */
+  sao->createEncData(false);
+  if (layer > 0) for (int c = 0; c < 3; c++) sao->m_saoDisabledRate[c][layer - 1] = disabledRate[c];
+  TEncSbac *goOn = new TEncSbac(); TEncBinCABACCounter *bin = new TEncBinCABACCounter(); TComBitCounter *bits = new TComBitCounter();
+  goOn->init(bin); bits->resetBits(); goOn->setBitstream(bits);
+  sao->initRDOCabacCoder(goOn, g_slice);
+  Bool enabled[MAX_NUM_COMPONENT];
+  sao->SAOProcess(g_pic, enabled, g_slice->getLambdas(), false);
+  SAOBlkParam *bp = g_pic->getPicSym()->getSAOBlkParam();
+  for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) {
+    int *o = out_params + (a * 3 + c) * 35; const SAOOffset &p = bp[a][ComponentID(c)];
+    o[0] = p.modeIdc; o[1] = p.typeIdc; o[2] = p.typeAuxInfo;
+    for (int k = 0; k < 32; k++) o[3 + k] = p.offset[k];
+    if (out_stats) for (int t = 0; t < NUM_SAO_NEW_TYPES; t++) {
+      long long *q = out_stats + ((a * 3 + c) * 5 + t) * 64; const SAOStatData &sd = sao->m_statData[a][c][t];
+      for (int k = 0; k < 32; k++) { q[k] = sd.diff[k]; q[32 + k] = sd.count[k]; }
+    }
+  }
+  for (int c = 0; c < 3; c++) { out_misc[c] = enabled[c] ? 1 : 0; out_rate[c] = sao->m_saoDisabledRate[c][layer]; }
+  return n;
 }
 
 } /* extern "C" */
