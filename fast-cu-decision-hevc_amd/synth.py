@@ -19,6 +19,22 @@ def smooth(width, height, seed=1234):
     return f(Y), f(U), f(V)
 
 
+def survey_frame(width=416, height=240, seed=1234):
+    """The frame of the survey's reference run of BASELINE config 0 (416x240, QP 32, 8448 bits, PSNR
+    32.3524 / 41.0897 / 41.1974 dB).  The survey describes it but did not keep the file; of the readings of
+    that description, this one -- chroma waves on luma coordinates, float -> uint8 by truncation -- is the one on which
+    decide -> deblock -> SAO reproduces all three PSNR values to the fourth decimal (tests/test_sao.py)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    Y = 128 + 40 * np.sin(x / 17) + 30 * np.cos(y / 11) + 20 * ((x // 32) % 2) + rng.normal(0, 6, (height, width))
+    Y[60:120, 100:220] += 50
+    cy, cx = np.mgrid[0:height // 2, 0:width // 2].astype(np.float64)
+    U = 128 + 20 * np.sin(2 * cx / 23) + rng.normal(0, 2, cy.shape)
+    V = 128 + 20 * np.cos(2 * cy / 19) + rng.normal(0, 2, cy.shape)
+    f = lambda a: np.clip(a, 0, 255).astype(np.uint8)
+    return f(Y), f(U), f(V)
+
+
 def textured(width, height, seed=7):
     rng = np.random.default_rng(seed)
     y, x = np.mgrid[0:height, 0:width].astype(np.float64)

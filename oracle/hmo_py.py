@@ -89,6 +89,8 @@ def load():
     lib.hmo_ctu_replay_bits.argtypes = [C.c_void_p, C.c_int]
     lib.hmo_deblock.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.hmo_deblock_pic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.hmo_sao_picture.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
+    lib.hmo_sao_stats.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hmo_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.hmo_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.hmo_decision_switch.argtypes = [C.c_void_p] * 5
@@ -244,6 +246,69 @@ def ldp_slice(poc, base_qp, gop=((3, 0.4624), (2, 0.4624), (3, 0.4624), (1, 0.57
     if not had_me:
         lam *= 0.95
     return SLICE_P, qp, lam
+
+
+def ldp_layer(poc, n=4):
+    """pic->getSlice(0)->getDepth(): temporal layer of picture `poc` inside its GOP (TEncSlice.cpp:236-262)"""
+    r = poc % n
+    if r == 0:
+        return 0
+    depth, step, i = 0, n, n >> 1
+    while i >= 1:
+        j = i
+        while j < n:
+            if j == r:
+                return depth + 1
+            j += step
+        step >>= 1
+        depth += 1
+        i >>= 1
+    return depth
+
+
+def slice_lambdas(qp, lam):
+    """TComSlice::getLambdas(): [lambda, lambda / w, lambda / w], w = 2^((QP - QPc) / 3) (TEncSlice::setUpLambda, TEncSlice.cpp:163-186)"""
+    p = Params()
+    load().hmo_params_default(C.byref(p), 64, 64, qp)
+    w = 2.0 ** ((qp - p.qp_c) / 3.0)
+    return [lam, lam / w, lam / w]
+
+
+SAO_DISABLE_RATE = (0.75, 0.5, 0.5)                         # SAO_ENCODING_RATE / _CHROMA, TypeDef.h:201-204
+
+
+class SaoState:
+    """m_saoDisabledRate of TEncSampleAdaptiveOffset across the pictures of a sequence (decidePicParams :363-395, update :895-917)"""
+
+    def __init__(self):
+        self.rate = np.zeros((3, 8), np.float64)
+
+    def enabled(self, layer):
+        return [0 if (layer > 0 and self.rate[c][layer - 1] > SAO_DISABLE_RATE[c]) else 1 for c in range(3)]
+
+    def update(self, layer, off_count, n_ctu):
+        for c in range(3):
+            self.rate[c][layer] = float(off_count[c]) / float(n_ctu)
+
+
+def sao_picture(org, rec, qp, slice_type, lam, enabled=(1, 1, 1), slice_ctus=0, want_stats=False):
+    """SAO of one deblocked picture, in place on `rec` (three uint8 planes).  Returns (params int32 [n_ctu, 3, 35] =
+    mode, type, aux, offset[32] as signalled; off_count[3]; stats int64 [n_ctu, 3, 2, 5, 32] (diff, count) or None)."""
+    lib = load()
+    h, w = org[0].shape
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    for a in list(org) + list(rec):
+        assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    po = (C.c_void_p * 3)(*[a.ctypes.data for a in org])
+    pr = (C.c_void_p * 3)(*[a.ctypes.data for a in rec])
+    lams = (C.c_double * 3)(*slice_lambdas(qp, lam))
+    en = (C.c_int * 3)(*[int(v) for v in enabled])
+    params = np.zeros((n, 3, 35), np.int32)
+    stats = np.zeros((n, 3, 2, 5, 32), np.int64) if want_stats else None
+    off = (C.c_int * 3)()
+    lib.hmo_sao_picture(w, h, slice_ctus, qp, slice_type, C.cast(lams, C.c_void_p), C.cast(en, C.c_void_p), C.cast(po, C.c_void_p), C.cast(pr, C.c_void_p),
+                        params.ctypes.data, stats.ctypes.data if want_stats else None, C.cast(off, C.c_void_p))
+    return params, list(off), stats
 
 
 def obf_prepass(Y):
