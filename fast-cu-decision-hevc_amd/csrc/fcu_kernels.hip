@@ -17,6 +17,7 @@
 #include "fcu_host.h"
 #include "fcu_obf.h"
 #include "fcu_deblock.h"
+#include "fcu_sao.h"
 
 using namespace fcu;
 
@@ -68,6 +69,8 @@ struct fcu_ctx {
   double ms_acc; int launches;
   /* persistent scratch of fcu_obf_prepass (grown on demand, freed by fcu_destroy) */
   unsigned *d_hist; size_t hist_cap; int *d_thr; size_t thr_cap;
+  /* persistent scratch of fcu_sao: picture descriptors, copy of the deblocked planes, statistics, candidates, reconstructed parameters, off counters */
+  void *d_sao; size_t sao_cap;
 };
 
 /* Launch timing keeps two events per launch until they are read.  A long-running caller that never asks for
@@ -118,7 +121,7 @@ int fcu_create(const fcu_seq_params *sp, fcu_ctx **out)
   fcu_ctx *c = new fcu_ctx();
   c->sp = *sp; c->n_ctu = ((sp->width + 63) / 64) * ((sp->height + 63) / 64);
   c->ms_acc = 0; c->launches = 0;
-  c->d_chains = nullptr; c->d_scratch = nullptr; c->d_hist = nullptr; c->hist_cap = 0; c->d_thr = nullptr; c->thr_cap = 0;
+  c->d_chains = nullptr; c->d_scratch = nullptr; c->d_hist = nullptr; c->hist_cap = 0; c->d_thr = nullptr; c->thr_cap = 0; c->d_sao = nullptr; c->sao_cap = 0;
   struct Guard { fcu_ctx *c; ~Guard() { if (c) { hipFree(c->d_chains); hipFree(c->d_scratch); delete c; } } } guard{ c };   /* frees on every early return */
   HIPCHK(hipMalloc((void **)&c->d_chains, sizeof(Chain) * (size_t)sp->max_chains));
   HIPCHK(hipMalloc((void **)&c->d_scratch, sizeof(Scratch) * (size_t)sp->max_chains));
@@ -137,7 +140,7 @@ void fcu_destroy(fcu_ctx *c)
   hipSetDevice(c->sp.device);
   hipDeviceSynchronize();
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
-  hipFree(c->d_chains); hipFree(c->d_scratch); hipFree(c->d_hist); hipFree(c->d_thr);
+  hipFree(c->d_chains); hipFree(c->d_scratch); hipFree(c->d_hist); hipFree(c->d_thr); hipFree(c->d_sao);
   delete c;
 }
 
@@ -172,6 +175,7 @@ void fcu_pad_sizes(const fcu_ctx *c, size_t *out3)
   out3[0] = (size_t)(c->sp.width + 2 * FCU_REF_MARGIN) * (size_t)(c->sp.height + 2 * FCU_REF_MARGIN);
   out3[1] = out3[2] = (size_t)(c->sp.width / 2 + FCU_REF_MARGIN) * (size_t)(c->sp.height / 2 + FCU_REF_MARGIN);
 }
+int fcu_ldp_layer(int poc) { static const int layer[4] = { 0, 2, 1, 2 }; return poc < 0 ? 0 : layer[poc & 3]; }
 
 int fcu_pad_reference(fcu_ctx *c, const uint8_t *dy, const uint8_t *du, const uint8_t *dv, uint8_t *py, uint8_t *pu, uint8_t *pv, void *hip_stream)
 {
@@ -461,6 +465,80 @@ int fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint
     hipEventElapsedTime(&kernel_ms2[0], e[0], e[1]); hipEventElapsedTime(&kernel_ms2[1], e[1], e[2]);
   }
   return FCU_OK;
+}
+
+int fcu_sao(fcu_ctx *c, int n_pics, const fcu_sao_params *params, const uint8_t *const *dev_org, uint8_t *const *dev_rec,
+            fcu_sao_ctu *dev_coded, int32_t *off_count, float *kernel_ms4, void *hip_stream)
+{
+  if (!c || n_pics <= 0 || !params || !dev_org || !dev_rec || !dev_coded) return fail(FCU_ERR_ARG, "fcu_sao: bad argument");
+  for (int i = 0; i < 3 * n_pics; i++) if (!dev_org[i] || !dev_rec[i]) return fail(FCU_ERR_ARG, "fcu_sao: null plane");
+  for (int i = 0; i < n_pics; i++) {
+    if (params[i].slice_type != FCU_SLICE_I && params[i].slice_type != FCU_SLICE_P) return fail(FCU_ERR_ARG, "fcu_sao: slice type");
+    if (params[i].qp < 0 || params[i].qp > 51 || params[i].slice_ctus < 0) return fail(FCU_ERR_ARG, "fcu_sao: qp / slice_ctus");
+    if (!(params[i].lambda[0] > 0) || params[i].lambda[1] < 0 || params[i].lambda[2] < 0) return fail(FCU_ERR_ARG, "fcu_sao: lambda[0] must be positive");
+  }
+  HIPCHK(hipSetDevice(c->sp.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int w = c->sp.width, h = c->sp.height, w_ctu = (w + 63) / 64, n_ctu = c->n_ctu;
+  const size_t plane[3] = { (size_t)w * h, (size_t)(w / 2) * (h / 2), (size_t)(w / 2) * (h / 2) }, pic_bytes = plane[0] + 2 * plane[1];
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_pics = 0, o_src = up(o_pics + sizeof(SaoPic) * n_pics), o_stats = up(o_src + pic_bytes * n_pics),
+               o_cand = up(o_stats + sizeof(int32_t) * SAO_STAT_INTS * 3 * (size_t)n_ctu * n_pics),
+               o_recon = up(o_cand + sizeof(SaoCand) * 15 * (size_t)n_ctu * n_pics),
+               o_off = up(o_recon + sizeof(fcu_sao_ctu) * (size_t)n_ctu * n_pics), total = up(o_off + sizeof(int32_t) * 3 * n_pics);
+  if (total > c->sao_cap) {
+    if (c->d_sao) { HIPCHK(hipStreamSynchronize(st)); hipFree(c->d_sao); c->d_sao = nullptr; c->sao_cap = 0; }
+    HIPCHK(hipMalloc(&c->d_sao, total)); c->sao_cap = total;
+  }
+  uint8_t *base = (uint8_t *)c->d_sao;
+  SaoPic *d_pics = (SaoPic *)(base + o_pics); int32_t *d_stats = (int32_t *)(base + o_stats); SaoCand *d_cand = (SaoCand *)(base + o_cand);
+  fcu_sao_ctu *d_recon = (fcu_sao_ctu *)(base + o_recon); int32_t *d_off = (int32_t *)(base + o_off);
+  std::vector<SaoPic> hp((size_t)n_pics);
+  for (int i = 0; i < n_pics; i++) {
+    uint8_t *s = base + o_src + pic_bytes * (size_t)i;
+    for (int k = 0; k < 3; k++) {
+      hp[i].org[k] = dev_org[3 * i + k]; hp[i].rec[k] = dev_rec[3 * i + k]; hp[i].src[k] = s;
+      HIPCHK(hipMemcpyAsync(s, dev_rec[3 * i + k], plane[k], hipMemcpyDeviceToDevice, st));      /* resYuv->copyToPic(srcYuv), :265 */
+      s += plane[k];
+      hp[i].enabled[k] = params[i].enabled[k] ? 1 : 0;
+    }
+    fcu_frame_params fp; default_frame_params(fp, params[i].qp); fp.lambda = params[i].lambda[0];
+    Params pp; fill_params(pp, w, h, fp);                      /* chroma lambdas = lambda / chroma weight (setUpLambda) unless given */
+    for (int k = 0; k < 3; k++) hp[i].lambda[k] = params[i].lambda[k] > 0 ? params[i].lambda[k] : pp.rdoq_lambda[k];
+    hp[i].slice_type = params[i].slice_type; hp[i].qp = params[i].qp; hp[i].slice_ctus = params[i].slice_ctus;
+  }
+  HIPCHK(hipMemcpyAsync(d_pics, hp.data(), sizeof(SaoPic) * n_pics, hipMemcpyHostToDevice, st));
+  hipEvent_t e[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  struct EventGuard { hipEvent_t *e; ~EventGuard() { for (int i = 0; i < 5; i++) if (e[i]) hipEventDestroy(e[i]); } } guard{ e };
+  if (kernel_ms4) { for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&e[i])); HIPCHK(hipEventRecord(e[0], st)); }
+  hipLaunchKernelGGL(sao_stats, dim3(n_ctu, 3, n_pics), dim3(SAO_THREADS), 0, st, d_pics, d_stats, w, h, w_ctu, n_ctu);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms4) HIPCHK(hipEventRecord(e[1], st));
+  const long long n_cand = (long long)n_pics * n_ctu * 15;
+  hipLaunchKernelGGL(sao_cands, dim3((unsigned)((n_cand + SAO_THREADS - 1) / SAO_THREADS)), dim3(SAO_THREADS), 0, st, d_pics, d_stats, d_cand, n_ctu, n_pics);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms4) HIPCHK(hipEventRecord(e[2], st));
+  hipLaunchKernelGGL(sao_decide, dim3((n_pics + 63) / 64), dim3(64), 0, st, d_pics, d_stats, d_cand, dev_coded, d_recon, d_off, w_ctu, n_ctu, n_pics);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms4) HIPCHK(hipEventRecord(e[3], st));
+  hipLaunchKernelGGL(sao_apply, dim3(n_ctu, 3, n_pics), dim3(SAO_THREADS), 0, st, d_pics, d_recon, w, h, w_ctu, n_ctu);
+  HIPCHK(hipGetLastError());
+  if (kernel_ms4) HIPCHK(hipEventRecord(e[4], st));
+  if (off_count) HIPCHK(hipMemcpyAsync(off_count, d_off, sizeof(int32_t) * 3 * n_pics, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));                          /* hp (the host descriptors) and off_count are done with */
+  if (kernel_ms4) for (int i = 0; i < 4; i++) hipEventElapsedTime(&kernel_ms4[i], e[i], e[i + 1]);
+  return FCU_OK;
+}
+
+void fcu_sao_enabled(const double rate[3][8], int layer, int32_t enabled[3])
+{
+  static const double thr[3] = { 0.75, 0.5, 0.5 };           /* SAO_ENCODING_RATE / SAO_ENCODING_RATE_CHROMA, TypeDef.h:201-204 */
+  for (int k = 0; k < 3; k++) enabled[k] = (layer > 0 && layer <= 8 && rate[k][layer - 1] > thr[k]) ? 0 : 1;
+}
+void fcu_sao_update_rate(double rate[3][8], int layer, const int32_t off_count[3], int num_ctus)
+{
+  if (layer < 0 || layer >= 8 || num_ctus <= 0) return;
+  for (int k = 0; k < 3; k++) rate[k][layer] = (double)off_count[k] / (double)num_ctus;
 }
 
 } /* extern "C" */

@@ -55,6 +55,21 @@ CTU_OUT_BYTES = C.sizeof(CtuOut)
 TRAINING, VERIFYING, TESTING = 0, 1, 2          # CurrentState (getCurrentState, tools_YS.cpp:1237-1242)
 
 
+class SaoOffset(C.Structure):
+    _fields_ = [("mode", C.c_int8), ("type", C.c_int8), ("band", C.c_int8), ("pad", C.c_int8), ("offset", C.c_int8 * 32)]
+
+
+class SaoCtu(C.Structure):
+    _fields_ = [("c", SaoOffset * 3)]
+
+
+class SaoParams(C.Structure):
+    _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("slice_ctus", C.c_int32), ("enabled", C.c_int32 * 3), ("lambda_", C.c_double * 3)]
+
+
+SAO_CTU_BYTES = C.sizeof(SaoCtu)
+
+
 class DecisionParams(C.Structure):
     """fcu_decision_params (include/fcu.h): frame state, Naive switches per depth, the frame's OBF map."""
     _fields_ = [("state", C.c_int), ("depth_exception", C.c_int), ("sw_skip2nx2n", C.c_uint8 * 4),
@@ -69,7 +84,8 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_compress_chains", "fcu_compress_ctu", "fcu_get_ctx_state", "fcu_chain_position", "fcu_sync",
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
-           "fcu_build_info", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full"]
+           "fcu_build_info", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full",
+           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer"]
 
 SLICE_I, SLICE_P = 0, 1
 REF_MARGIN = 80
@@ -125,6 +141,12 @@ def load_lib():
     lib.fcu_decision_switch.argtypes = [C.POINTER(VerifyCounts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcu_frame_state.argtypes = [C.c_int] * 4
     lib.fcu_deblock.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+    lib.fcu_sao.argtypes = [C.c_void_p, C.c_int, C.POINTER(SaoParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+    lib.fcu_sao_enabled.restype = None
+    lib.fcu_sao_enabled.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.fcu_sao_update_rate.restype = None
+    lib.fcu_sao_update_rate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.fcu_ldp_layer.argtypes = [C.c_int]
     _lib = lib
     return lib
 
@@ -142,6 +164,33 @@ def decision_switch(ver, th_skip=(0, 0, 0, 0), th_term=(0, 0, 0, 0)):
     sk, te = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
     lib.fcu_decision_switch(C.byref(v), ts.ctypes.data, tt.ctypes.data, sk.ctypes.data, te.ctypes.data)
     return sk, te
+
+
+def sao_coded_to_array(coded):
+    """uint8 [.., n_ctu, SAO_CTU_BYTES] (device tensor or array) -> int32 [.., n_ctu, 3, 35]: mode, type, band, offset[32]"""
+    a = coded.cpu().numpy() if hasattr(coded, "cpu") else np.asarray(coded)
+    a = a.view(np.int8).reshape(a.shape[:-1] + (3, 36)).astype(np.int32)
+    return np.concatenate([a[..., :3], a[..., 4:]], axis=-1)
+
+
+class SaoRate:
+    """m_saoDisabledRate across the pictures of one sequence (fcu_sao_enabled / fcu_sao_update_rate)"""
+
+    def __init__(self):
+        self.rate = np.zeros((3, 8), np.float64)
+
+    def enabled(self, layer):
+        e = np.zeros(3, np.int32)
+        load_lib().fcu_sao_enabled(self.rate.ctypes.data, layer, e.ctypes.data)
+        return [int(v) for v in e]
+
+    def update(self, layer, off_count, n_ctu):
+        oc = np.ascontiguousarray(off_count, np.int32)
+        load_lib().fcu_sao_update_rate(self.rate.ctypes.data, layer, oc.ctypes.data, n_ctu)
+
+
+def ldp_layer(poc):
+    return load_lib().fcu_ldp_layer(poc)
 
 
 def ldp_slice(base_qp, poc):
@@ -354,6 +403,34 @@ class CuEngine:
         self._chk(self.lib.fcu_deblock(self.h, out.data_ptr(), rec[0].data_ptr(), rec[1].data_ptr(), rec[2].data_ptr(),
                                        beta_offset_div2, tc_offset_div2, ms, s), "fcu_deblock")
         return (ms[0], ms[1]) if timed else None
+
+    # -- TEncSampleAdaptiveOffset::SAOProcess
+    def sao(self, pictures, timed=False, stream=None):
+        """SAO of completely decided, deblocked pictures, in place on their reconstruction planes.  pictures: list of dicts
+        {org: (Y,U,V) device tensors, rec: (Y,U,V) device tensors, qp, lambda_ (the slice's luma lambda), slice_type,
+        slice_ctus, enabled (3 ints, default all on), chroma_weight (default: from the QP, chroma QP offset 0)}.  Returns (coded uint8 tensor
+        [n, n_ctu, SAO_CTU_BYTES] on the device, off_count int32 array [n, 3], kernel ms x4 or None)."""
+        torch = self.torch
+        n = len(pictures)
+        dev = torch.device("cuda", self.device)
+        prm = (SaoParams * n)()
+        org, rec = (C.c_void_p * (3 * n))(), (C.c_void_p * (3 * n))()
+        for i, p in enumerate(pictures):
+            w = p.get("chroma_weight")
+            prm[i].slice_type, prm[i].qp, prm[i].slice_ctus = p.get("slice_type", SLICE_I), p["qp"], p.get("slice_ctus", 0)
+            lam = p["lambda_"]
+            for k in range(3):
+                prm[i].enabled[k] = int(p.get("enabled", (1, 1, 1))[k])
+                prm[i].lambda_[k] = lam if k == 0 else (lam / w if w else 0.0)
+                for t in (p["org"][k], p["rec"][k]):
+                    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.numel() == (self.width >> (1 if k else 0)) * (self.height >> (1 if k else 0))
+                org[3 * i + k], rec[3 * i + k] = p["org"][k].data_ptr(), p["rec"][k].data_ptr()
+        coded = torch.zeros((n, self.n_ctu, SAO_CTU_BYTES), dtype=torch.uint8, device=dev)
+        off = np.zeros((n, 3), np.int32)
+        ms = (C.c_float * 4)() if timed else None
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._chk(self.lib.fcu_sao(self.h, n, prm, org, rec, coded.data_ptr(), off.ctypes.data, ms, s), "fcu_sao")
+        return coded, off, (list(ms) if timed else None)
 
     # -- TEncCu::destroy
     def destroy(self):

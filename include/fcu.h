@@ -22,6 +22,9 @@
  *      tools_YS.cpp:686-695,968-986,1123-1154,1237)   (getCurrentState)
  *   TComLoopFilter::loopFilterPic                  fcu_deblock (in-loop deblocking of the decided picture)
  *     (TComLoopFilter.cpp:130, TEncGOP.cpp:1160)
+ *   TEncSampleAdaptiveOffset::SAOProcess           fcu_sao (statistics, per-CTU parameter decision, offset pass) +
+ *     (TEncSampleAdaptiveOffset.cpp:257,              fcu_sao_enabled / fcu_sao_update_rate (decidePicParams and the
+ *      TEncGOP.cpp:1427-1441)                         m_saoDisabledRate bookkeeping across pictures, :363-395,895-917)
  *   m_pppcRDSbacCoder[0][CI_CURR_BEST] state      fcu_get_ctx_state
  *     (TEncSlice.cpp:1417,1477)
  *
@@ -116,6 +119,9 @@ void fcu_pad_sizes(const fcu_ctx *c, size_t *out3);
  * 0.4624 x3, 0.578) as TEncSlice::initEncSlice derives them (TEncSlice.cpp:560-740): fills fp->qp / lambda / slice_type and the
  * configuration defaults (SearchRange 64, FEN, HadamardME, FDM, MaxNumMergeCand 5).  Pure host arithmetic. */
 void fcu_ldp_slice(fcu_frame_params *fp, int base_qp, int poc);
+/* pic->getSlice(0)->getDepth() of picture `poc` under that table (GOPSize 4; TEncSlice.cpp:236-262): 0, 2, 1, 2 for
+ * poc % 4 = 0..3 -- the temporal layer fcu_sao_enabled / fcu_sao_update_rate key on */
+int  fcu_ldp_layer(int poc);
 /* Restrict a bound chain to the CTUs [first_ctu, first_ctu + n_ctus) of its frame.  Both ends must be slice
  * boundaries (frame_params.slice_ctus), where HM resets the entropy coder (TEncSlice.cpp:1392-1395) and masks the
  * neighbourhood (TComDataCU::getPULeft/Above): the slices of ONE frame then run as independent chains that share
@@ -186,6 +192,34 @@ int  fcu_frame_state(int poc, int period, int n_training, int n_verifying);
  * asynchronous unless kernel_ms2 is given, which then receives the durations of the vertical- and horizontal-edge pass. */
 int  fcu_deblock(fcu_ctx *c, const fcu_ctu_out *dev_out, uint8_t *dev_rec_y, uint8_t *dev_rec_u, uint8_t *dev_rec_v,
                  int beta_offset_div2, int tc_offset_div2, float *kernel_ms2, void *hip_stream);
+/* ---- sample adaptive offset --------------------------------------------------------------------------------------
+ * SAOOffset / SAOBlkParam of the reference (TypeDef.h:760-800) narrowed to bytes: mode 0 off / 1 new / 2 merge;
+ * type: edge class 0..3 or 4 = band offset for a new mode, 0 = left / 1 = above for a merge; band = band position;
+ * offset[class]: EO offsets at [0,1,3,4] (class 2 is always 0), BO offsets at [band .. band+3] (mod 32). */
+typedef struct { int8_t mode, type, band, pad; int8_t offset[32]; } fcu_sao_offset;
+typedef struct { fcu_sao_offset c[3]; } fcu_sao_ctu;                    /* Y, Cb, Cr */
+typedef struct {
+  int32_t slice_type;        /* FCU_SLICE_I / FCU_SLICE_P: context initialisation of the SAO syntax */
+  int32_t qp;                /* slice QP */
+  int32_t slice_ctus;        /* SliceArgument (0 = one slice): merge candidates do not cross slices */
+  int32_t enabled[3];        /* slice-level switches (fcu_sao_enabled) */
+  double  lambda[3];         /* TComSlice::getLambdas(): lambda, lambda / chroma weight (x2); [1], [2] = 0: derived from [0] and the QP (chroma QP offsets 0) */
+} fcu_sao_params;
+/* TEncSampleAdaptiveOffset::SAOProcess (TEncSampleAdaptiveOffset.cpp:257-287; TEncGOP.cpp:1427-1441, SaoCtuBoundary 0) of
+ * n_pics completely decided and deblocked pictures of this context's size, in place on their reconstruction planes.
+ * dev_org / dev_rec: host arrays of 3 * n_pics device pointers (Y, U, V of picture 0, then picture 1 ...);
+ * dev_coded: device array [n_pics][num_ctus] receiving the parameters as signalled (what the adapter stores into
+ * TComPicSym::getSAOBlkParam()); off_count (host, 3 * n_pics, may be NULL): CTUs whose reconstructed mode is off, per
+ * component -- the input of fcu_sao_update_rate.  Four kernels on `hip_stream`; the call returns after they have finished
+ * (off_count and kernel_ms4 -- statistics, candidates, decision, offset pass -- are read back).  No CPU fallback. */
+int  fcu_sao(fcu_ctx *c, int n_pics, const fcu_sao_params *params, const uint8_t *const *dev_org, uint8_t *const *dev_rec,
+             fcu_sao_ctu *dev_coded, int32_t *off_count, float *kernel_ms4, void *hip_stream);
+/* decidePicParams (:363-395): enabled[comp] = 0 when the picture's temporal layer is > 0 and the share of SAO-off CTUs in
+ * layer - 1 exceeded 0.75 (luma) / 0.5 (chroma).  rate = m_saoDisabledRate[3][8], zero-initialised by the caller per sequence. */
+void fcu_sao_enabled(const double rate[3][8], int layer, int32_t enabled[3]);
+/* the bookkeeping at the end of decideBlkParams (:895-917) */
+void fcu_sao_update_rate(double rate[3][8], int layer, const int32_t off_count[3], int num_ctus);
+
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);
 /* text of the calling thread's last failure (one buffer per host thread) */
