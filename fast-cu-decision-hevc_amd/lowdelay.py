@@ -5,7 +5,8 @@ slice parameters -> compressSlice -> loop filter -> reference for the next pictu
 Pictures of ONE clip are strictly sequential (every P picture needs the filtered reconstruction of its predecessor), so
 the parallelism of a launch comes from the slices of a picture and from independent clips side by side: clip s, slice k
 is chain s * n_slices + k.  Per picture: fcu_ldp_slice (QP / lambda of HM's lowdelay_P GOP table) -> fcu_chain_begin
-(+ fcu_chain_set_reference for P) -> one fcu_compress_chains launch over all chains -> fcu_deblock -> fcu_pad_reference.
+(+ fcu_chain_set_reference for P) -> one fcu_compress_chains launch over all chains -> fcu_deblock -> fcu_sao (SAO 1, the
+reference's lowdelay configuration; one batched call for all clips) -> fcu_pad_reference.
 Across GPUs the reference picture is the only data a rank would need from another one (one copy per picture, SURVEY.md 8e);
 with whole clips per rank there is none.
 """
@@ -18,13 +19,15 @@ class LowDelayPDecider:
     """`n_clips` clips of width x height decided picture by picture on one GPU.
     slice_ctus: CTUs per slice (HM SliceMode 1); None = one slice per picture (the reference configuration)."""
 
-    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, device=0):
+    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, device=0):
         self.width, self.height, self.base_qp, self.n_clips, self.search_range = width, height, base_qp, n_clips, search_range
         n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
         self.slice_ctus = slice_ctus if slice_ctus else n_ctu
         self.n_slices = (n_ctu + self.slice_ctus - 1) // self.slice_ctus
         self.eng = _engine.CuEngine(width, height, max_chains=n_clips * self.n_slices, device=device)
         self.do_deblock = deblock
+        self.do_sao = sao                                # SAO 1 of the reference's cfg; off by default: the loop-filter goldens stop at deblocking
+        self.sao_rate = [_engine.SaoRate() for _ in range(n_clips)]      # m_saoDisabledRate per clip
         self.poc = 0
         self.ref = [None] * n_clips                      # padded reference planes per clip
 
@@ -35,8 +38,8 @@ class LowDelayPDecider:
 
     def decide_picture(self, frames):
         """frames: one (Y, U, V) per clip for picture self.poc.  Returns per clip a dict: poc, slice_type, qp, `out` (the
-        fcu_ctu_out array as a uint8 device tensor), `rec` (device planes, deblocked when enabled), `rec_unfiltered`
-        (a copy before the loop filter, for parity checks)."""
+        fcu_ctu_out array as a uint8 device tensor), `rec` (device planes after the loop filters that are enabled), `rec_unfiltered`
+        (a copy before the loop filters, for parity checks), `sao` (the picture's fcu_sao_ctu array when SAO is on)."""
         eng, poc = self.eng, self.poc
         assert len(frames) == self.n_clips
         fp = self.frame_params(poc)
@@ -58,6 +61,15 @@ class LowDelayPDecider:
             r["rec_unfiltered"] = [p.clone() for p in r["rec"]]
             if self.do_deblock:
                 eng.deblock(r["first"])
+        if self.do_sao:
+            layer = _engine.ldp_layer(poc)
+            pics = [{"org": eng._keep[r["first"]][0], "rec": r["rec"], "qp": fp.qp, "lambda_": fp.lambda_, "slice_type": fp.slice_type,
+                     "slice_ctus": self.slice_ctus if self.n_slices > 1 else 0, "enabled": self.sao_rate[s].enabled(layer)} for s, r in enumerate(res)]
+            coded, off, _ = eng.sao(pics)
+            for s, r in enumerate(res):
+                r["sao"], r["sao_enabled"] = coded[s], pics[s]["enabled"]
+                self.sao_rate[s].update(layer, off[s], eng.n_ctu)
+        for s, r in enumerate(res):
             self.ref[s] = eng.pad_reference(r["rec"])          # reference of the next picture of this clip
         eng.sync()
         self.poc += 1
