@@ -1,0 +1,262 @@
+/*
+ * TEncCuFcu.cpp -- drop-in replacement of TLibEncoder/TEncCu.cpp for HM-16.3 / the Fast-CU-Decision fork: the six public
+ * methods of class TEncCu (TLibEncoder/TEncCu.h:104-118) implemented over libfcu.so, plus the protected members the
+ * bitstream pass needs (xEncodeCU / finishCU).  The maintainer builds HM with this file instead of TEncCu.cpp and links
+ * libfcu.so + the HIP runtime; nothing else in HM changes: TEncSlice::compressSlice keeps calling compressCtu / encodeCtu per
+ * CTU (TEncSlice.cpp:1468,1482) and encodeSlice keeps calling encodeCtu (TEncSlice.cpp:1707).
+ *
+ *   compressCtu : the CU depth / mode RDO of one CTU on the GPU.  Slice setup happens here, on the first CTU of a slice
+ *                 (source planes once per picture, reference picture of a P slice, QP / lambdas from the objects
+ *                 TEncSlice::initEncSlice / setUpLambda have prepared, chain range = the slice).  The result is written where
+ *                 xCompressCU leaves it: the CTU's TComDataCU arrays, PicYuvRec, and the contexts of
+ *                 m_pppcRDSbacCoder[0][CI_CURR_BEST] are advanced by the device as compressSlice expects
+ *                 (the engine replays encodeCtu on its own coder; HM's own replay at TEncSlice.cpp:1474-1487 still runs on
+ *                 the host with the marshalled data and arrives at the same state).
+ *   encodeCtu   : HM's syntax walk over the decided CTU with whatever entropy coder is attached -- written here from the
+ *                 syntax order of the standard (7.3.8.4 / 7.3.8.5), as TEncCu.cpp:359-373,1679-1778 has it.
+ *   PicYuvPred  : not written.  The fork's xCopyYuv2Pic also stores the best prediction there (TEncCu.cpp:2298); nothing in
+ *                 Lib/ or App/ reads TComPic::getPicYuvPred() (grep), so the plane is dead output.
+ * Only the fork's default control is behind the ABI (Training state = HM's exhaustive RDO, or the Naive decision switches
+ * through fcu_chain_set_decision); see INTEGRATION.md for the per-picture calls around this class.
+ *
+ * Compile check in this repository (no HM build system is run):  adapter/build_check.sh
+ */
+#include <vector>
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <hip/hip_runtime_api.h>
+#include "TLibEncoder/TEncTop.h"
+#include "TLibEncoder/TEncCu.h"
+#include "fcu_marshal.h"
+
+namespace {
+
+/* device side of one encoder instance (TEncCu is a singleton inside TEncTop; HM encodes one picture at a time) */
+struct FcuState {
+  fcu_ctx *ctx = nullptr;
+  int width = 0, height = 0, n_ctu = 0;
+  uint8_t *d_org[3] = { nullptr, nullptr, nullptr }, *d_rec[3] = { nullptr, nullptr, nullptr }, *d_ref[3] = { nullptr, nullptr, nullptr };
+  uint8_t *d_refsrc[3] = { nullptr, nullptr, nullptr };
+  fcu_ctu_out *d_out = nullptr;
+  std::vector<uint8_t> h_plane[3];
+  Int poc_loaded = -1 << 30;
+  fcu_ctu_out h_out;
+};
+FcuState g_fcu;
+
+void die(const char *what, int rc) { fprintf(stderr, "TEncCuFcu: %s failed (%d): %s\n", what, rc, fcu_last_error()); exit(1); }   /* no CPU fallback */
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "TEncCuFcu: %s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+size_t plane_bytes(int w, int h, int c) { return c ? (size_t)(w / 2) * (h / 2) : (size_t)w * h; }
+
+void ensure_context(const TComSPS *sps)
+{
+  FcuState &S = g_fcu;
+  const int w = (int)sps->getPicWidthInLumaSamples(), h = (int)sps->getPicHeightInLumaSamples();
+  if (S.ctx && S.width == w && S.height == h) return;
+  if (sps->getChromaFormatIdc() != CHROMA_420 || sps->getBitDepth(CHANNEL_TYPE_LUMA) != 8 || sps->getMaxCUWidth() != 64) { fprintf(stderr, "TEncCuFcu: 8-bit 4:2:0 with 64x64 CTUs only\n"); exit(1); }
+  fcu_seq_params sp = { w, h, /*max_chains*/ 1, /*device*/ 0 };
+  int rc = fcu_create(&sp, &S.ctx);
+  if (rc != FCU_OK) die("fcu_create", rc);
+  S.width = w; S.height = h; S.n_ctu = fcu_num_ctus(S.ctx);
+  size_t pad[3]; fcu_pad_sizes(S.ctx, pad);
+  for (int c = 0; c < 3; c++) {
+    HIPOK(hipMalloc((void **)&S.d_org[c], plane_bytes(w, h, c))); HIPOK(hipMalloc((void **)&S.d_rec[c], plane_bytes(w, h, c)));
+    HIPOK(hipMalloc((void **)&S.d_refsrc[c], plane_bytes(w, h, c))); HIPOK(hipMalloc((void **)&S.d_ref[c], pad[c]));
+    S.h_plane[c].resize(plane_bytes(w, h, c));
+  }
+  HIPOK(hipMalloc((void **)&S.d_out, sizeof(fcu_ctu_out) * (size_t)S.n_ctu));
+}
+
+void upload(TComPicYuv *pic, uint8_t *const d[3])
+{
+  FcuState &S = g_fcu;
+  for (int c = 0; c < 3; c++) {
+    fcu_adapter::narrow_plane(pic, ComponentID(c), S.h_plane[c].data());
+    HIPOK(hipMemcpy(d[c], S.h_plane[c].data(), S.h_plane[c].size(), hipMemcpyHostToDevice));
+  }
+}
+
+/* first CTU of a slice: bind the chain to the picture with the slice's parameters and restrict it to the slice */
+void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cfg)
+{
+  FcuState &S = g_fcu;
+  TComPic *pic = pCtu->getPic(); TComSlice *slice = pCtu->getSlice();
+  ensure_context(slice->getSPS());
+  if (pic->getPOC() != S.poc_loaded) {                          /* once per picture: the source planes */
+    upload(pic->getPicYuvOrg(), S.d_org);
+    S.poc_loaded = pic->getPOC();
+  }
+  fcu_frame_params fp;
+  fcu_default_frame_params(&fp, slice->getSliceQp());
+  fp.lambda = rd->getLambda(); fp.sqrt_lambda = rd->getSqrtLambda(); fp.chroma_weight = rd->getChromaWeight();   /* TEncSlice::setUpLambda */
+  for (int c = 0; c < 3; c++) fp.rdoq_lambda[c] = slice->getLambdas()[c];
+  const TComPPS *pps = slice->getPPS();
+  fp.transform_skip = pps->getUseTransformSkip(); fp.transform_skip_fast = cfg->getUseTransformSkipFast();
+  fp.sign_hiding = pps->getSignHideFlag(); fp.strong_intra_smoothing = slice->getSPS()->getUseStrongIntraSmoothing();
+  const int first = (int)pic->getPicSym()->getCtuTsToRsAddrMap(slice->getSliceCurStartCtuTsAddr());
+  const int count = (int)(slice->getSliceCurEndCtuTsAddr() - slice->getSliceCurStartCtuTsAddr());
+  fp.slice_ctus = cfg->getSliceMode() == FIXED_NUMBER_OF_CTU ? cfg->getSliceArgument() : 0;
+  if (!slice->isIntra()) {
+    if (slice->isInterB() || slice->getNumRefIdx(REF_PIC_LIST_0) != 1) { fprintf(stderr, "TEncCuFcu: P slices with one reference picture only\n"); exit(1); }
+    fp.slice_type = FCU_SLICE_P;
+    fp.search_range = cfg->getSearchRange(); fp.fast_enc = cfg->getUseFastEnc(); fp.hadamard_me = cfg->getUseHADME();
+    fp.fast_merge_decision = cfg->getUseFastDecisionForMerge(); fp.max_merge_cand = slice->getMaxNumMergeCand();
+  }
+  int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
+  if (rc != FCU_OK) die("fcu_chain_begin", rc);
+  if (fp.slice_type == FCU_SLICE_P) {                           /* list 0, index 0: the filtered reconstruction HM holds */
+    upload(slice->getRefPic(REF_PIC_LIST_0, 0)->getPicYuvRec(), S.d_refsrc);
+    rc = fcu_pad_reference(S.ctx, S.d_refsrc[0], S.d_refsrc[1], S.d_refsrc[2], S.d_ref[0], S.d_ref[1], S.d_ref[2], nullptr);
+    if (rc != FCU_OK) die("fcu_pad_reference", rc);
+    rc = fcu_chain_set_reference(S.ctx, 0, S.d_ref[0], S.d_ref[1], S.d_ref[2]);
+    if (rc != FCU_OK) die("fcu_chain_set_reference", rc);
+  }
+  if (fp.slice_ctus > 0) { rc = fcu_chain_set_range(S.ctx, 0, first, count); if (rc != FCU_OK) die("fcu_chain_set_range", rc); }
+}
+
+} /* namespace */
+
+/* ---- the six public methods ------------------------------------------------------------------------------------------ */
+
+Void TEncCu::init(TEncTop *pcEncTop)
+{
+  m_pcEncCfg = pcEncTop;
+  m_pcPredSearch = pcEncTop->getPredSearch();
+  m_pcTrQuant = pcEncTop->getTrQuant();
+  m_pcRdCost = pcEncTop->getRdCost();
+  m_pcEntropyCoder = pcEncTop->getEntropyCoder();
+  m_pcBinCABAC = pcEncTop->getBinCABAC();
+  m_pppcRDSbacCoder = pcEncTop->getRDSbacCoder();
+  m_pcRDGoOnSbacCoder = pcEncTop->getRDGoOnSbacCoder();
+  m_pcRateCtrl = pcEncTop->getRateCtrl();
+}
+
+Void TEncCu::create(UChar uhTotalDepth, UInt, UInt, ChromaFormat)
+{
+  /* the per-depth best / temp CU and YUV buffers of TEncCu.cpp live in device memory now (csrc/fcu_engine.h: Scratch);
+   * the context needs the picture size, which arrives with the first slice (ensure_context) */
+  m_uhTotalDepth = uhTotalDepth + 1;
+  m_ppcBestCU = m_ppcTempCU = NULL;
+  m_ppcPredYuvBest = m_ppcResiYuvBest = m_ppcRecoYuvBest = m_ppcPredYuvTemp = m_ppcResiYuvTemp = m_ppcRecoYuvTemp = m_ppcOrigYuv = NULL;
+  m_bEncodeDQP = false; m_CodeChromaQpAdjFlag = false; m_ChromaQpAdjIdc = 0;
+}
+
+Void TEncCu::destroy()
+{
+  FcuState &S = g_fcu;
+  for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_ref[c]); hipFree(S.d_refsrc[c]); S.d_org[c] = S.d_rec[c] = S.d_ref[c] = S.d_refsrc[c] = nullptr; }
+  hipFree(S.d_out); S.d_out = nullptr;
+  if (S.ctx) { fcu_destroy(S.ctx); S.ctx = nullptr; }
+  S.width = S.height = 0; S.poc_loaded = -1 << 30;
+}
+
+Void TEncCu::compressCtu(TComDataCU *pCtu)
+{
+  FcuState &S = g_fcu;
+  TComPic *pic = pCtu->getPic(); TComSlice *slice = pCtu->getSlice();
+  const UInt rs = pCtu->getCtuRsAddr();
+  if (rs == pic->getPicSym()->getCtuTsToRsAddrMap(slice->getSliceCurStartCtuTsAddr())) begin_slice(pCtu, m_pcRdCost, m_pcTrQuant, m_pcEncCfg);
+  const int rc = fcu_compress_ctu(S.ctx, 0, rs, &S.h_out);      /* compressCtu + the context replay of encodeCtu, result to the host */
+  if (rc != FCU_OK) die("fcu_compress_ctu", rc);
+  fcu_adapter::marshal_ctu(S.h_out, pCtu);
+  /* PicYuvRec: the CTU's block of the three planes (neighbouring CTUs and the loop filter read it on the host) */
+  const UInt wc = pic->getFrameWidthInCtus();
+  const int x0 = (int)(rs % wc) * 64, y0 = (int)(rs / wc) * 64;
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, w = S.width >> sh, bx = x0 >> sh, by = y0 >> sh, bw = std::min(64 >> sh, w - bx), bh = std::min(64 >> sh, (S.height >> sh) - by);
+    HIPOK(hipMemcpy2D(S.h_plane[c].data() + (size_t)by * w + bx, (size_t)w, S.d_rec[c] + (size_t)by * w + bx, (size_t)w, (size_t)bw, (size_t)bh, hipMemcpyDeviceToHost));
+    fcu_adapter::widen_ctu_block(S.h_plane[c].data(), pic->getPicYuvRec(), ComponentID(c), rs, wc);
+  }
+}
+
+Void TEncCu::encodeCtu(TComDataCU *pCtu)
+{
+  if (pCtu->getSlice()->getPPS()->getUseDQP()) setdQPFlag(true);
+  if (pCtu->getSlice()->getUseChromaQpAdj()) setCodeChromaQpAdjFlag(true);
+  xEncodeCU(pCtu, 0, 0);
+}
+
+/* rate control's intra complexity of a CTU: sum over its whole 8x8 blocks of the original luma of the 8x8 Hadamard
+ * amplitude without DC, (sum + 2) >> 2 per block (TEncCu.cpp:1792-1893) */
+Int TEncCu::updateCtuDataISlice(TComDataCU *pCtu, Int width, Int height)
+{
+  const Pel *org = pCtu->getPic()->getPicYuvOrg()->getAddr(COMPONENT_Y, pCtu->getCtuRsAddr(), 0);
+  const Int stride = pCtu->getPic()->getPicYuvOrg()->getStride(COMPONENT_Y);
+  Int total = 0;
+  for (Int by = 0; by + 8 <= height; by += 8) for (Int bx = 0; bx + 8 <= width; bx += 8) {
+    Int m[64];
+    for (Int y = 0; y < 8; y++) for (Int x = 0; x < 8; x++) m[y * 8 + x] = org[(by + y) * stride + bx + x];
+    for (Int pass = 0; pass < 2; pass++) {                     /* rows, then columns: three butterfly stages each */
+      const Int step = pass ? 8 : 1, line = pass ? 1 : 8;
+      for (Int l = 0; l < 8; l++) for (Int span = 4; span >= 1; span >>= 1)
+        for (Int base = 0; base < 8; base += 2 * span) for (Int k = 0; k < span; k++) {
+          Int &a = m[l * line + (base + k) * step], &b = m[l * line + (base + k + span) * step];
+          const Int s = a + b, d = a - b; a = s; b = d;
+        }
+    }
+    Int sum = 0;
+    for (Int i = 1; i < 64; i++) sum += abs(m[i]);
+    total += (sum + 2) >> 2;
+  }
+  return total;
+}
+
+/* ---- bitstream pass over a decided CTU -------------------------------------------------------------------------------- */
+
+/* end of a coding unit: every CTU but the last of its slice segment ends with a zero terminating bin */
+Void TEncCu::finishCU(TComDataCU *pcCU, UInt uiAbsPartIdx, UInt)
+{
+  if (!pcCU->isLastSubCUOfCtu(uiAbsPartIdx)) return;
+  TComPic *pic = pcCU->getPic();
+  const TComSlice *slice = pic->getSlice(pic->getCurrSliceIdx());
+  const Int ts = (Int)pic->getPicSym()->getCtuRsToTsAddrMap(pcCU->getCtuRsAddr());
+  if ((Int)slice->getSliceSegmentCurEndCtuTsAddr() != ts + 1) m_pcEntropyCoder->encodeTerminatingBit(0);
+}
+
+/* coding_quadtree() / coding_unit() of the CTU in the order of the standard.  A node inside the picture signals its split
+ * flag; a node that crosses the picture border is split without one, and children that start outside do not exist. */
+Void TEncCu::xEncodeCU(TComDataCU *pcCU, UInt uiAbsPartIdx, UInt uiDepth)
+{
+  const TComSlice *slice = pcCU->getSlice();
+  const TComSPS *sps = slice->getSPS(); const TComPPS *pps = slice->getPPS();
+  const UInt size = g_uiMaxCUWidth >> uiDepth, raster = g_auiZscanToRaster[uiAbsPartIdx];
+  const UInt x = pcCU->getCUPelX() + g_auiRasterToPelX[raster], y = pcCU->getCUPelY() + g_auiRasterToPelY[raster];
+  const Bool inside = x + size <= sps->getPicWidthInLumaSamples() && y + size <= sps->getPicHeightInLumaSamples();
+  if (inside) m_pcEntropyCoder->encodeSplitFlag(pcCU, uiAbsPartIdx, uiDepth);
+  const Bool dqpLevel = pps->getUseDQP() && size == (g_uiMaxCUWidth >> pps->getMaxCuDQPDepth());
+  const Bool cqaLevel = slice->getUseChromaQpAdj() && size == (g_uiMaxCUWidth >> pps->getMaxCuChromaQpAdjDepth());
+  if (!inside || (uiDepth < pcCU->getDepth(uiAbsPartIdx) && uiDepth < g_uiMaxCUDepth - g_uiAddCUDepth)) {
+    if (dqpLevel) setdQPFlag(true);
+    if (cqaLevel) setCodeChromaQpAdjFlag(true);
+    const UInt quarter = (pcCU->getPic()->getNumPartitionsInCtu() >> (2 * uiDepth)) >> 2;
+    for (UInt k = 0; k < 4; k++) {
+      const UInt part = uiAbsPartIdx + k * quarter, r = g_auiZscanToRaster[part];
+      if (pcCU->getCUPelX() + g_auiRasterToPelX[r] < sps->getPicWidthInLumaSamples() && pcCU->getCUPelY() + g_auiRasterToPelY[r] < sps->getPicHeightInLumaSamples())
+        xEncodeCU(pcCU, part, uiDepth + 1);
+    }
+    return;
+  }
+  if (pps->getUseDQP() && size >= (g_uiMaxCUWidth >> pps->getMaxCuDQPDepth())) setdQPFlag(true);
+  if (slice->getUseChromaQpAdj() && size >= (g_uiMaxCUWidth >> pps->getMaxCuChromaQpAdjDepth())) setCodeChromaQpAdjFlag(true);
+  if (pps->getTransquantBypassEnableFlag()) m_pcEntropyCoder->encodeCUTransquantBypassFlag(pcCU, uiAbsPartIdx);
+  if (!slice->isIntra()) m_pcEntropyCoder->encodeSkipFlag(pcCU, uiAbsPartIdx);
+  if (pcCU->isSkipped(uiAbsPartIdx)) {
+    m_pcEntropyCoder->encodeMergeIndex(pcCU, uiAbsPartIdx);
+    finishCU(pcCU, uiAbsPartIdx, uiDepth);
+    return;
+  }
+  m_pcEntropyCoder->encodePredMode(pcCU, uiAbsPartIdx);
+  m_pcEntropyCoder->encodePartSize(pcCU, uiAbsPartIdx, uiDepth);
+  if (pcCU->isIntra(uiAbsPartIdx) && pcCU->getPartitionSize(uiAbsPartIdx) == SIZE_2Nx2N) {
+    m_pcEntropyCoder->encodeIPCMInfo(pcCU, uiAbsPartIdx);
+    if (pcCU->getIPCMFlag(uiAbsPartIdx)) { finishCU(pcCU, uiAbsPartIdx, uiDepth); return; }
+  }
+  m_pcEntropyCoder->encodePredInfo(pcCU, uiAbsPartIdx);
+  Bool codeDQP = getdQPFlag(), codeCQA = getCodeChromaQpAdjFlag();
+  m_pcEntropyCoder->encodeCoeff(pcCU, uiAbsPartIdx, uiDepth, codeDQP, codeCQA);
+  setCodeChromaQpAdjFlag(codeCQA);
+  setdQPFlag(codeDQP);
+  finishCU(pcCU, uiAbsPartIdx, uiDepth);
+}

@@ -1404,11 +1404,11 @@ FCU_DEV FCU_NOINLINE void cu_copy_to_pic(const CuObj *cu)                       
 {
   const Env E = env_get(); cu = FCU_UNI(cu);
   fcu_ctu_out *p = &E.C->out[E.cur_ctu];
-  const int n = cu->nparts, off = cu->zidx, s = CTU >> cu->depth_cu, qp = E.C->p.qp;
+  const int n = cu->nparts, off = cu->zidx, qp = E.C->p.qp;
   FCU_FOR_LANES {
     if (lane == 0) { p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins; }
     for (int i = lane; i < n; i += 64) {
-      p->depth[off + i] = cu->depth[i]; p->width[off + i] = (uint8_t)s; p->height[off + i] = (uint8_t)s; p->skip[off + i] = cu->skip[i];
+      p->depth[off + i] = cu->depth[i]; p->width[off + i] = p->height[off + i] = (uint8_t)(CTU >> cu->depth[i]);   /* the sub-CUs' own sizes */ p->skip[off + i] = cu->skip[i];
       p->merge_flag[off + i] = cu->merge_flag[i]; p->merge_idx[off + i] = cu->merge_idx[i]; p->inter_dir[off + i] = cu->inter_dir[i];
       p->mvp_idx[off + i] = cu->mvp_idx[i]; p->ref_idx[off + i] = cu->ref_idx[i];
       p->mv[off + i][0] = cu->mv[i][0]; p->mv[off + i][1] = cu->mv[i][1]; p->mvd[off + i][0] = cu->mvd[i][0]; p->mvd[off + i][1] = cu->mvd[i][1];

@@ -107,10 +107,10 @@ static void cu_copy_part_from(HmoCU *dst, const HmoCU *src, int partUnitIdx)
 static void cu_copy_to_pic(HmoEnc *e, const HmoCU *cu)
 {
   HmoCtu *p = &e->pic[e->cur_ctu];
-  int n = cu->nparts, off = cu->zidx, s = cu_size(cu);
+  int n = cu->nparts, off = cu->zidx;
   p->total_cost = cu->cost; p->total_dist = cu->dist; p->total_bits = cu->bits; p->total_bins = cu->bins;
   memcpy(p->depth + off, cu->depth, (size_t)n);
-  memset(p->width + off, s, (size_t)n); memset(p->height + off, s, (size_t)n);
+  for (int i = 0; i < n; i++) p->width[off + i] = p->height[off + i] = (uint8_t)(HMO_CTU >> cu->depth[i]);   /* the sub-CUs' own sizes (m_puhWidth / m_puhHeight are copied per partition) */
   memcpy(p->skip + off, cu->skip, (size_t)n);
   memcpy(p->merge_flag + off, cu->merge_flag, (size_t)n); memcpy(p->merge_idx + off, cu->merge_idx, (size_t)n);
   memcpy(p->inter_dir + off, cu->inter_dir, (size_t)n); memcpy(p->mvp_idx + off, cu->mvp_idx, (size_t)n); memcpy(p->ref_idx + off, cu->ref_idx, (size_t)n);

@@ -51,10 +51,21 @@ if [ ! -f "$o" ] || [ "$s" -nt "$o" ]; then
 fi
 objs="$objs $o"
 for p in $pids; do wait $p; done
+# the HM adapter of this repository (adapter/TEncCuFcu.cpp: TEncCu's public methods over libfcu.so) is compiled against the
+# same headers and linked in, so that tests can push fcu_ctu_out data through its marshalling into a real TComDataCU and
+# through its encodeCtu walk into the reference's own TEncEntropy (ref_adapter_* in ref_driver.cpp)
+PKG="$HERE/../../fast-cu-decision-hevc_amd"
+ADP="$HERE/../../adapter"
+a="$OUT/obj/TEncCuFcu.o"
+if [ ! -f "$a" ] || [ "$ADP/TEncCuFcu.cpp" -nt "$a" ] || [ "$ADP/fcu_marshal.h" -nt "$a" ] || [ "$HERE/../../include/fcu.h" -nt "$a" ]; then
+  g++ $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ADP" -I"$HERE/../../include" -include <(fix) -include limits -c "$ADP/TEncCuFcu.cpp" -o "$a"
+fi
+objs="$objs $a"
 gcc -O2 -w -fPIC -c "$REF/Lib/libmd5/libmd5.c" -o "$OUT/obj/libmd5.o"
-g++ $FLAGS -include <(fix) -include limits -I"$HERE" -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
+g++ $FLAGS -include <(fix) -include limits -I"$HERE" -I"$ADP" -I"$HERE/../../include" -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
 cat > "$OUT/obj/export.map" <<'MAP'
 { global: ref_*; _Z21TCMprocessOneSequencePiiS_PdS0_S0_; _Z14FindStartPointP7tBucketii; _Z17ComputeLikelyhoodiiP7tBucketi; _Z20ComputeLambdaGivenYcddd; local: *; };
 MAP
-g++ -shared -o "$OUT/libhmleaf.so" $objs "$OUT/obj/libmd5.o" "$OUT/obj/ref_driver.o" -Wl,--gc-sections -Wl,--version-script="$OUT/obj/export.map" -Wl,-z,defs
+g++ -shared -o "$OUT/libhmleaf.so" $objs "$OUT/obj/libmd5.o" "$OUT/obj/ref_driver.o" -Wl,--gc-sections -Wl,--version-script="$OUT/obj/export.map" -Wl,-z,defs \
+    -L"$PKG" -lfcu -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../../fast-cu-decision-hevc_amd' -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/libhmleaf.so"

@@ -45,10 +45,13 @@
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncSearch.h"
 #include "TLibEncoder/TEncSampleAdaptiveOffset.h"
+#include "TLibEncoder/TEncTop.h"
+#include "TLibEncoder/TEncCu.h"
 #undef private
 #undef protected
 #include <math.h>
 #include <string.h>
+#include "fcu_marshal.h"
 
 /* Every object of the reference that this driver creates starts from zeroed memory: several reference classes leave
  * members to their owner (TEncTop::init -- not built -- sets e.g. TComRdCost::m_costMode, the TEncCfg fields), and a
@@ -627,6 +630,27 @@ int ref_sao(int sliceType, int qp, const double *lambdas, int slice_ctus, int la
   }
   for (int c = 0; c < 3; c++) { out_misc[c] = enabled[c] ? 1 : 0; out_rate[c] = sao->m_saoDisabledRate[c][layer]; }
   return n;
+}
+
+/* ---- the HM adapter of this repository (adapter/TEncCuFcu.cpp, adapter/fcu_marshal.h) against the reference's classes ----
+ * ref_adapter_marshal: fcu_ctu_out bytes -> the picture's TComDataCU of that CTU through the adapter's own marshalling.
+ * ref_adapter_encode_ctu: the adapter's TEncCu::encodeCtu (its xEncodeCU / finishCU walk) on the reference's TEncEntropy
+ * with the bit counter attached, as TEncSlice::compressSlice runs it after compressCtu (TEncSlice.cpp:1474-1487). */
+static TEncCu *g_cuEnc = 0;
+void ref_adapter_marshal(int ctu, const void *ctu_out) { fcu_adapter::marshal_ctu(*(const fcu_ctu_out *)ctu_out, g_pic->getCtu(ctu)); }
+void ref_adapter_encode_ctu(int ctu)
+{
+  if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); }
+  g_cuEnc->m_pcEntropyCoder = g_ent;
+  g_cuEnc->encodeCtu(g_pic->getCtu(ctu));
+}
+int ref_adapter_isl_cost(int ctu, int w, int h) { if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); } return g_cuEnc->updateCtuDataISlice(g_pic->getCtu(ctu), w, h); }
+/* planes through the adapter's converters: 8-bit plane -> PicYuvRec block by block (widen_ctu_block), and back (narrow_plane) */
+void ref_adapter_planes_roundtrip(int comp, const unsigned char *in, unsigned char *out)
+{
+  const ComponentID c = ComponentID(comp);
+  for (UInt a = 0; a < g_pic->getNumberOfCtusInFrame(); a++) fcu_adapter::widen_ctu_block(in, g_pic->getPicYuvRec(), c, a, g_pic->getFrameWidthInCtus());
+  fcu_adapter::narrow_plane(g_pic->getPicYuvRec(), c, out);
 }
 
 } /* extern "C" */
