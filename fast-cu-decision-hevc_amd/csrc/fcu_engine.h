@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define FCU_DEV static inline
+#define FCU_MEMBER inline
 #define FCU_NOINLINE
 #define FCU_INLINE
 #define FCU_TABLE static const
@@ -74,6 +75,7 @@ template <class T> static inline T fcu_emu_uni(T v, int site, int line)
 #define FCU_CHECK(c) do { if (!(c)) { fprintf(stderr, "FCU_CHECK failed: %s (line %d)\n", #c, __LINE__); abort(); } } while (0)
 #else
 #define FCU_DEV __device__ static
+#define FCU_MEMBER __device__ inline
 #define FCU_NOINLINE __noinline__
 #define FCU_INLINE __attribute__((always_inline))
 #define FCU_TABLE __device__ static const
@@ -269,15 +271,22 @@ struct Shared {
   /* hot coders, one LDS array so that coder ids index it directly:
    * [CAB_GOON] go-on coder, [CAB_CUR0+d] = [depth][CI_CURR_BEST], [CAB_LANE0+k] lane-private trial coders */
   Cabac cab[1 + (MAXDEPTH + 1) + MAXLC];
-  union {                                           /* luma reference samples / scratch copy of the chroma sets: never live together */
-    struct { uint8_t ref[264], reff[264]; };
-    uint8_t ref5b[5][68];
-  };
   uint8_t ref5[5][68]; int dc5[5]; uint32_t cm_dist[5];     /* chroma: per-mode reference samples (N <= 16) */
-  union {                                           /* never live at the same time */
+  /* Three tenants that are never live together (8 KB of LDS per chain = 20 chains per CU, five waves per SIMD):
+   *  - reference samples of the block being predicted (+ the availability flags that build them): dead once the
+   *    predictions of the batch are in the candidate pools, i.e. before any quantisation;
+   *  - the records of the coefficient group in flight in the serial RDOQ;
+   *  - the |level| lists of the lane-private bit counters. */
+  union {
     int16_t lane_abs[MAXLC][32];                    /* per lane: |level| list of the coefficient group being coded [0..15], the group's levels [16..31] */
-    int32_t colsum[128];                            /* availability flags of build_ref / chroma_leaf_refs5 */
     RdoqRec rq_rec[16];                             /* serial RDOQ: records of the coefficient group in flight */
+    struct {
+      int32_t colsum[128];                          /* availability flags of build_ref / chroma_leaf_refs5 */
+      union {                                       /* luma reference samples / scratch copy of the chroma sets */
+        struct { uint8_t ref[264], reff[264]; };
+        uint8_t ref5b[5][68];
+      };
+    };
   };
   union {
     int16_t rq_lv[16];                              /* serial RDOQ: levels of the coefficient group in flight */
@@ -290,7 +299,8 @@ struct Shared {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
     int uni[8];                                                       /* chroma leaf: transform-skip choice per mode */
   };
-  uint32_t est[NCTX_INTRA * 2];                      /* [159] (the pad context) carries rqt_root_cbf for inter luma; estBit table of the coder RDOQ prices against: bits[ctx][bin] (TEncSbac.cpp:1722-1956) */
+/* est: the estBit table of the coder RDOQ prices against, bits[ctx][bin] (TEncSbac.cpp:1722-1956), lives in the upper
+   * lane coders (FCU_EST below): it is built and read before the bit count that loads them; [159] (the pad context) carries rqt_root_cbf for inter luma */
   union {                                           /* intra candidate batch / inter mailboxes: never live at the same time */
     struct {
       uint8_t vc_slot[MAXVC];                       /* lane coder that holds a variant's state after the bit count */
@@ -324,6 +334,11 @@ struct Shared {
 };
 
 enum { CAB_GOON = 0, CAB_CUR0 = 1, CAB_LANE0 = 1 + (MAXDEPTH + 1) };
+/* RDOQ's rate table (NCTX_INTRA x 2 words) borrows lane coders [MAXLC-7, MAXLC): est_build() fills it before the RDOQ of a
+ * batch, the bit count that follows is the first to load those coders, and nothing reads the table afterwards. */
+enum { EST_CODERS = 7 };
+static_assert(EST_CODERS * sizeof(Cabac) >= NCTX_INTRA * 2 * sizeof(uint32_t) && EST_CODERS <= MAXLC, "est table does not fit its lane coders");
+#define FCU_EST ((uint32_t *)&g_S.cab[CAB_LANE0 + MAXLC - EST_CODERS])
 #ifdef FCU_EMU
 static Shared g_S;
 #else
@@ -425,7 +440,7 @@ FCU_DEV int ctx_bits(int cid, int ctx, int bin) { return (int)(g_hot.bin[FCU_CB.
 /* TEncSbac::estBit: the costs of both bins of every context of coder `cid`, one LDS word each; called by all lanes
  * in the phase before RDOQ (the contexts are frozen while RDOQ runs) */
 enum { EST_ROOT_CBF = NCTX_INTRA - 1 };
-FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX_INTRA * 2; i += 64) { const int cx = (i >> 1) == EST_ROOT_CBF ? CTX_ROOT_CBF : (i >> 1); g_S.est[i] = g_hot.bin[FCU_CB.ctx[cx] * 2 + (i & 1)] >> 8; } }
+FCU_DEV void est_build(int cid, int lane) { for (int i = lane; i < NCTX_INTRA * 2; i += 64) { const int cx = (i >> 1) == EST_ROOT_CBF ? CTX_ROOT_CBF : (i >> 1); FCU_EST[i] = g_hot.bin[FCU_CB.ctx[cx] * 2 + (i & 1)] >> 8; } }
 
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3356-3411 */
 FCU_DEV int coef_scan_idx(int dir, int log2, int comp)
@@ -704,7 +719,7 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   if (topNZ < 0) { RdoqOut z = { 0, -1 }; return z; }            /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
   const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
   FCU_HBM RdoqRec *recg = (FCU_HBM RdoqRec *)rec; FCU_HBM double *cgg = (FCU_HBM double *)costCGSig;
-  auto cb = [&](int ctx, int bin) -> int { return EST ? (int)g_S.est[ctx * 2 + bin] : ctx_bits(c, ctx, bin); };
+  auto cb = [&](int ctx, int bin) -> int { return EST ? (int)FCU_EST[ctx * 2 + bin] : ctx_bits(c, ctx, bin); };
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? P.qp_c : P.qp;
   const int qbits = rdoq_qbits(log2, qp);
@@ -1097,6 +1112,32 @@ FCU_DEV int32_t dot_row(const int8_t *m, const T *a)
   for (int n = 0; n < N; n++) s += (int32_t)(int8_t)(mw[n >> 2] >> (8 * (n & 3))) * (int32_t)a[n];
   return s;
 }
+/* The input line of a lane's dot products, held in registers across the iterations of an element loop.  Every caller walks
+ * its outputs with a stride of 64 lanes, and 64 is a multiple of N: inside one block a lane keeps meeting the same input
+ * line (N of them per block, every one feeding N outputs).  Re-reading the line per output made each pass stream its whole
+ * N x N tile N * N / 64 times through L1 / L2 -- 16 x for 32x32 -- and with thousands of resident chains that stream lands
+ * in HBM.  A lane (re)loads its line only when the line's address changes (next candidate block).  The input arrays are
+ * never written during the phase that reads them, so the copy cannot go stale; a cache lives for one phase only. */
+template <int N, class T> struct RowCache {
+  T v[N]; const T *src;
+  FCU_MEMBER RowCache() : src(nullptr) {}
+  FCU_MEMBER const T *get(const T *p)
+  {
+    if (p != src) { src = p; __builtin_memcpy(v, (const T *)__builtin_assume_aligned(p, sizeof(T) * N >= 16 ? 16 : 8), sizeof(v)); }
+    return v;
+  }
+};
+template <int N, class T>
+FCU_DEV int32_t dot_regs(const int8_t *m, const T *a)         /* a: a RowCache line (registers) */
+{
+  m = (const int8_t *)__builtin_assume_aligned(m, N >= 16 ? 16 : N);
+  uint32_t mw[N / 4];
+  __builtin_memcpy(mw, m, N);
+  int32_t s = 0;
+#pragma unroll
+  for (int n = 0; n < N; n++) s += (int32_t)(int8_t)(mw[n >> 2] >> (8 * (n & 3))) * (int32_t)a[n];
+  return s;
+}
 /* size dispatch OUTSIDE the element loops: f(std::integral_constant<int, log2>) */
 template <class F>
 FCU_DEV void by_log2(int log2, F f)
@@ -1119,6 +1160,14 @@ template <int LOG2> FCU_DEV int32_t inv1(const int32_t *deqT, int useDst, int id
 { constexpr int N = 1 << LOG2; const int y = idx >> LOG2, kh = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, y), deqT + (kh << LOG2)) + 64) >> 7); }
 template <int LOG2> FCU_DEV int32_t inv2(const int32_t *tmp2, int useDst, int idx)
 { constexpr int N = 1 << LOG2; const int y = idx >> LOG2, x = idx & (N - 1); return clip3i(-32768, 32767, (dot_row<N>(basis_col<LOG2>(useDst, x), tmp2 + (y << LOG2)) + 2048) >> 12); }
+/* three of the four passes with the lane's input line cached (declare one RowCache per element loop) */
+template <int LOG2> FCU_DEV int32_t fwd1(RowCache<(1 << LOG2), int16_t> &rc, const int16_t *resi, int useDst, int idx)
+{ constexpr int N = 1 << LOG2, s1 = LOG2 - 1; const int k = idx >> LOG2, y = idx & (N - 1); return (dot_regs<N>(basis_row<LOG2>(useDst, k), rc.get(resi + (y << LOG2))) + (1 << (s1 - 1))) >> s1; }
+template <int LOG2> FCU_DEV int32_t fwd2(RowCache<(1 << LOG2), int32_t> &rc, const int32_t *tmp, int useDst, int idx)
+{ constexpr int N = 1 << LOG2, s2 = LOG2 + 6; const int k2 = idx >> LOG2, k1 = idx & (N - 1); return (dot_regs<N>(basis_row<LOG2>(useDst, k2), rc.get(tmp + (k1 << LOG2))) + (1 << (s2 - 1))) >> s2; }
+template <int LOG2> FCU_DEV int32_t inv1(RowCache<(1 << LOG2), int32_t> &rc, const int32_t *deqT, int useDst, int idx)
+{ constexpr int N = 1 << LOG2; const int y = idx >> LOG2, kh = idx & (N - 1); return clip3i(-32768, 32767, (dot_regs<N>(basis_col<LOG2>(useDst, y), rc.get(deqT + (kh << LOG2))) + 64) >> 7); }
+/* (inv2's input line follows the high index bits: neighbouring lanes share it, one broadcast read per iteration) */
 struct DeqParams { int scale, rs, lo, hi; };                /* xDeQuant flat, TComTrQuant.cpp:1242-1352: loop invariants of one TU */
 FCU_DEV DeqParams deq_params(int log2, int qp)
 {
@@ -1510,8 +1559,8 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
   const uint16_t *iscan = k_iscan + k_scan_off[scanType * 4 + log2 - 2];
   if (useTS) { FCU_FOR_LANES { est_build(cab, lane); for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double((int32_t)G->p_resi[i] << (15 - 8 - log2), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } } }
   else {
-    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi, useDst, i); }); }
-    FCU_FOR_LANES { est_build(cab, lane); by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<decltype(L)::value>(G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
+    FCU_FOR_LANES { by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1<LG>(rc, G->p_resi, useDst, i); }); }
+    FCU_FOR_LANES { est_build(cab, lane); by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<LG>(rc, G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
   }
   FCU_FOR_LANES {
     if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
@@ -1537,7 +1586,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
   if (absSum > 0) {
     if (useTS) { FCU_FOR_LANES { const int s = 15 - 8 - log2; for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)((G->p_tmp[i] + (1 << (s - 1))) >> s); } }
     else {
-      FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp, useDst, i); }); }
+      FCU_FOR_LANES { by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int i = lane; i < n2; i += 64) G->p_tcoef[i] = inv1<LG>(rc, G->p_tmp, useDst, i); }); }
       FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < n2; i += 64) G->p_resi[i] = (int16_t)inv2<decltype(L)::value>(G->p_tcoef, useDst, i); }); }
     }
   }
@@ -1875,14 +1924,14 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
       G->p_pred[i] = (uint8_t)v; G->p_resi[i] = (int16_t)(org[y * 64 + x] - v);
     }
   }
-  FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + cnd * n2, useDst, i - cnd * n2); } }); }
+  FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<LG>(rc, G->p_resi + cnd * n2, useDst, i - cnd * n2); } }); }
   FCU_FOR_LANES {                                            /* slot v = cand*tsv + ts */
     est_build(CAB_CUR0 + d, lane);
-    by_log2(log2, [&](auto L) {
+    by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc;
       for (int i = lane; i < nvc * n2; i += 64) {
         const int v = i / n2, p = i - v * n2, cnd = (v >> tss), ts = (v & tss);
         const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[cnd], log2, 0) * 4 + log2 - 2];
-        const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + cnd * n2, useDst, p);
+        const int32_t t = ts ? ((int32_t)G->p_resi[cnd * n2 + p] << (15 - 8 - log2)) : fwd2<LG>(rc, G->p_tmp + cnd * n2, useDst, p);
         const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
         G->p_lscan[sp * nvc + v] = ld;
         if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
@@ -1913,11 +1962,11 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
     }
   }
   FCU_FOR_LANES {
-    by_log2(log2, [&](auto L) {
+    by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc;
       for (int i = lane; i < nvc * n2; i += 64) {
         const int v = i / n2, p = i - v * n2, ts = (v & tss);
         if (ts) { const int s = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (s - 1))) >> s; }
-        else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, useDst, p);
+        else G->p_tcoef[i] = inv1<LG>(rc, G->p_tmp + v * n2, useDst, p);
       }
     });
   }
@@ -2032,13 +2081,13 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
         }
       }
     }
-    FCU_FOR_LANES { if (lane < nc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + cnd * n2, 0, i - cnd * n2); } }); }
+    FCU_FOR_LANES { if (lane < nc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int i = lane; i < nc * n2; i += 64) { const int cnd = i / n2; G->p_tmp[i] = fwd1<LG>(rc, G->p_resi + cnd * n2, 0, i - cnd * n2); } }); }
     FCU_FOR_LANES {
-      by_log2(log2, [&](auto L) {
+      by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc;
         for (int i = lane; i < nc * n2; i += 64) {
           const int v = i / n2, p = i - v * n2;
           const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(g_S.rd_mode[v], log2, 0) * 4 + log2 - 2];
-          const int32_t t = fwd2<decltype(L)::value>(G->p_tmp + v * n2, 0, p);
+          const int32_t t = fwd2<LG>(rc, G->p_tmp + v * n2, 0, p);
           const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
           G->p_lscan[sp * nc + v] = ld;
           if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
@@ -2065,7 +2114,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
         G->p_tmp[v * n2 + tr_index(p, log2)] = dequant1(q, dq);
       }
     }
-    FCU_FOR_LANES { by_log2(log2, [&](auto L) { for (int i = lane; i < nc * n2; i += 64) { const int v = i / n2; G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, 0, i - v * n2); } }); }
+    FCU_FOR_LANES { by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int i = lane; i < nc * n2; i += 64) { const int v = i / n2; G->p_tcoef[i] = inv1<LG>(rc, G->p_tmp + v * n2, 0, i - v * n2); } }); }
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
         for (int i = lane; i < nc * n2; i += 64) {
@@ -2310,14 +2359,14 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
         }
       }
     }
-    FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { for (int i = lane; i < nm * n2; i += 64) { const int b = i / n2; G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + b * n2, 0, i - b * n2); } }); }
+    FCU_FOR_LANES { if (lane < nvc) g_S.vc_last[lane] = -1; by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int i = lane; i < nm * n2; i += 64) { const int b = i / n2; G->p_tmp[i] = fwd1<LG>(rc, G->p_resi + b * n2, 0, i - b * n2); } }); }
     FCU_FOR_LANES {
-      by_log2(log2, [&](auto L) {
+      by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc;
         for (int i = lane; i < nvc * n2; i += 64) {
           const int v = i / n2, p = i - v * n2, b = (v >> tss), ts = (v & tss), m = b % 5, comp = comp0 + b / 5;
           const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
           const uint16_t *iscan = k_iscan + k_scan_off[coef_scan_idx(mode, log2, comp) * 4 + log2 - 2];
-          const int32_t t = ts ? ((int32_t)G->p_resi[b * n2 + p] << (15 - 8 - log2)) : fwd2<decltype(L)::value>(G->p_tmp + b * n2, 0, p);
+          const int32_t t = ts ? ((int32_t)G->p_resi[b * n2 + p] << (15 - 8 - log2)) : fwd2<LG>(rc, G->p_tmp + b * n2, 0, p);
           const int sp = iscan[p]; const int32_t ld = level_double(t, qscale, qbits);
           G->p_lscan[sp * nvc + v] = ld;
           if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.vc_last[v], sp);
@@ -2349,11 +2398,11 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
       }
     }
     FCU_FOR_LANES {
-      by_log2(log2, [&](auto L) {
+      by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc;
         for (int i = lane; i < nvc * n2; i += 64) {
           const int v = i / n2, p = i - v * n2, ts = (v & tss);
           if (ts) { const int sft = 15 - 8 - log2; G->p_tcoef[i] = (G->p_tmp[i] + (1 << (sft - 1))) >> sft; }
-          else G->p_tcoef[i] = inv1<decltype(L)::value>(G->p_tmp + v * n2, 0, p);
+          else G->p_tcoef[i] = inv1<LG>(rc, G->p_tmp + v * n2, 0, p);
         }
       });
     }

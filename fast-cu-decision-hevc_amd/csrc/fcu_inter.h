@@ -565,11 +565,9 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
   }
   FCU_FOR_LANES {
     uint32_t z[3] = { 0, 0, 0 };
-    for (int i = lane; i < btot; i += 64) {
-      const int b = i < boff[1] ? 0 : (i < boff[2] ? 1 : 2), k = i - boff[b];
-      const int r = G->p_resi[i]; z[b] += (uint32_t)(r * r);
-      by_log2(bl2[b], [&](auto L) { G->p_tmp[i] = fwd1<decltype(L)::value>(G->p_resi + boff[b], 0, k); });
-    }
+    for (int i = lane; i < btot; i += 64) { const int b = i < boff[1] ? 0 : (i < boff[2] ? 1 : 2); const int r = G->p_resi[i]; z[b] += (uint32_t)(r * r); }
+    for (int b = 0; b < ncomp; b++)
+      by_log2(bl2[b], [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int k = lane; k < bN[b] * bN[b]; k += 64) G->p_tmp[boff[b] + k] = fwd1<LG>(rc, G->p_resi + boff[b], 0, k); });
     for (int b = 0; b < 3; b++) FCU_WAVE_ADD(&g_S.acc[6 + b], z[b]);
   }
   FCU_FOR_LANES {                                            /* second stage -> level_double in scan order (SCAN_DIAG) */
@@ -579,14 +577,13 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       const int comp = v >> 1, N = bN[comp], l2 = bl2[comp], n2 = N * N, o = voff(v);
       const int qp = comp ? P.qp_c : P.qp, qbits = rdoq_qbits(l2, qp), qscale = k_quant_scales[qp % 6];
       const uint16_t *iscan = k_iscan + k_scan_off[0 * 4 + l2 - 2];
-      for (int k = lane; k < n2; k += 64) {
-        int32_t t;
-        if (v & 1) t = (int32_t)G->p_resi[boff[comp] + k] << (15 - 8 - l2);
-        else by_log2(l2, [&](auto L) { t = fwd2<decltype(L)::value>(G->p_tmp + boff[comp], 0, k); });
+      auto put = [&](int k, int32_t t) {
         const int sp = iscan[k]; const int32_t ld = level_double(t, qscale, qbits);
         G->p_lscan[o + sp] = ld;
         if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.iv_top[v], sp);
-      }
+      };
+      if (v & 1) { for (int k = lane; k < n2; k += 64) put(k, (int32_t)G->p_resi[boff[comp] + k] << (15 - 8 - l2)); }
+      else by_log2(l2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int k = lane; k < n2; k += 64) put(k, fwd2<LG>(rc, G->p_tmp + boff[comp], 0, k)); });
     }
   }
   /* RDOQ: one variant per lane, all priced against the snapshot.  rdoq() and code_coeff_nxn() take block size and
@@ -616,7 +613,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
     for (int v = 0; v < 6; v++) {
       if (!vok(v) || g_S.iv_abs[v] <= 0 || (v & 1)) continue;
       const int comp = v >> 1, l2 = bl2[comp], n2 = bN[comp] * bN[comp], o = voff(v);
-      by_log2(l2, [&](auto L) { for (int k = lane; k < n2; k += 64) G->p_tcoef[o + k] = inv1<decltype(L)::value>(G->p_tmp + 2048 + o, 0, k); });
+      by_log2(l2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int k = lane; k < n2; k += 64) G->p_tcoef[o + k] = inv1<LG>(rc, G->p_tmp + 2048 + o, 0, k); });
     }
   }
   FCU_FOR_LANES {                                            /* reconstructed residual of every variant + its SSE against the residual */

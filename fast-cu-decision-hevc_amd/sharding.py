@@ -29,3 +29,24 @@ def reduce_step_time(dist, local_seconds, device=None):
     t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def slice_owner(n_ctu, slice_ctus, world):
+    """owner rank of every slice of a picture under slices_for_rank (contiguous runs of whole slices)"""
+    n_sl = (n_ctu + slice_ctus - 1) // slice_ctus
+    per = (n_sl + world - 1) // world
+    return [min(k // per, world - 1) for k in range(n_sl)]
+
+
+def merge_picture(dist, planes, out):
+    """The one exchange step of a picture whose slices were decided on different ranks (inter hand-off):
+    every rank wrote only its own slices' CTUs into zero-initialised reconstruction planes and fcu_ctu_out array, so the
+    element-wise SUM over ranks is the complete picture on every rank (uint8 all-reduce over RCCL / xGMI, 12.4 MB of
+    planes + the decision array per 4K picture).  Every rank then runs the loop filters on the whole picture itself
+    (deblocking and SAO are cheap, data-parallel kernels) and pads its own copy of the reference: one collective per
+    picture, no second broadcast.  Order per picture: decide own slices -> merge_picture -> deblock -> SAO -> pad ->
+    next picture.  `planes`: three uint8 tensors, `out`: uint8 tensor; merged in place.  No-op without a process group."""
+    if dist is None:
+        return
+    for t in list(planes) + [out]:
+        dist.all_reduce(t)
