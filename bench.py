@@ -30,7 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 1024 + rec 12288 + coeff 24576 + meta 5120
-ALGO_BYTES_PER_CTU_LDP = 55300 + 3 * 4096 * 3 // 2   # + the reference samples of the three part-size searches' windows' core (one 64x64 4:2:0 block each)
+# lowdelay_P adds the reference samples a CTU's search can touch, read once: the luma window (64 + 2 * SearchRange)^2 and the
+# two chroma blocks with their interpolation margin 2 x (32 + 8)^2 -- SURVEY.md 8(d) gives no figure for configs[4]; DESIGN.md 3e
+algo_bytes_ldp = lambda sr: ALGO_BYTES_PER_CTU + (64 + 2 * sr) ** 2 + 2 * (32 + 8) ** 2
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
@@ -268,7 +270,7 @@ def main():
 
     if rank == 0:
         per_launch = timed_ctus_gpu / max(1, args.steps)
-        algo = ALGO_BYTES_PER_CTU_LDP if ldp else ALGO_BYTES_PER_CTU
+        algo = algo_bytes_ldp(args.search_range) if ldp else ALGO_BYTES_PER_CTU
         achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
@@ -291,8 +293,8 @@ def main():
                        f"testing (Naive switches skip2Nx2N={switches[0].tolist()} terminate={switches[1].tolist()} from a Verifying step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profile_commit": prof_commit,
-                         "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches,
-                         "note": "the kernel is latency / issue bound (serial CABAC + RDOQ per chain), not HBM bound: see DESIGN.md 3"},
+                         "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_ctu": algo,
+                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about 3.5 TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3"},
         }
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if world == 1 and not args.no_cpu_baseline:
