@@ -214,6 +214,7 @@ struct Chain {
   uint8_t sw_skip[4], sw_term[4];
   const int16_t *obf;
   double ver[4][6];
+  fcu_pu_trace *pu_trace;      /* optional [n_ctu][FCU_PUS_PER_CTU] record of the luma search (fcu_chain_set_pu_trace) */
 };
 enum { DEC_TRAINING = 0, DEC_VERIFYING = 1, DEC_TESTING = 2 };
 
@@ -2166,6 +2167,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
 /* ======================================================================================== */
 /* estIntraPredLumaQT, TEncSearch.cpp:2178-2655                                               */
 /* ======================================================================================== */
+FCU_DEV int pu_trace_index(int depth, int nxn, int zidx) { return nxn ? 85 + zidx : (depth == 0 ? 0 : depth == 1 ? 1 + (zidx >> 6) : depth == 2 ? 5 + (zidx >> 4) : 21 + (zidx >> 2)); }   /* = fcu_pu_index (include/fcu.h) */
 FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
 {
   const Env E = env_get(); cu = FCU_UNI(cu);
@@ -2180,6 +2182,13 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
     const int partOffset = tu.part, N = 1 << tu.log2, log2 = tu.log2;
     FCU_SERIAL g_S.c64_valid = 0;
     { FCU_TIC(t_); rmd(cu, tu_key(tu)); FCU_TOC(E, t_, 0); }
+    fcu_pu_trace *ptr = FCU_UNI(E.C->pu_trace ? E.C->pu_trace + (size_t)E.cur_ctu * FCU_PUS_PER_CTU + pu_trace_index(d, initTrDepth, cu->zidx + partOffset) : (fcu_pu_trace *)nullptr);
+    if (ptr) FCU_SERIAL {                                    /* candidate list and CandCostList as the RMD leaves them */
+      const int nRmd = k_rd_mode_num[log2 - 2];
+      ptr->n_rmd = (uint8_t)nRmd; ptr->n_rd = (uint8_t)g_S.n_rd; ptr->pad = 0;
+      for (int i = 0; i < 12; i++) ptr->rd_mode[i] = (uint8_t)(i < g_S.n_rd ? g_S.rd_mode[i] : 0);
+      for (int i = 0; i < 8; i++) ptr->rmd_cost[i] = i < nRmd ? g_S.cand_cost[i] : 0.0;
+    }
     const int singleTU = log2 <= LOG2_MAXTU;                /* first pass never splits such a PU */
     if (singleTU) { FCU_TIC(t_); pu_first_pass_batched(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }
     else if (g_S.n_rd <= 5) { FCU_TIC(t_); pu_first_pass_64(cu, tu_key(tu)); FCU_TOC(E, t_, 1); }   /* 64x64: four 32x32 TUs, candidates side by side */
@@ -2212,6 +2221,7 @@ FCU_DEV FCU_NOINLINE void est_intra_pred_luma(CuObj *cu)
     }
     overallDistY += g_S.pu_best_dist;
     const int bestMode = g_S.pu_best_mode;
+    if (ptr) FCU_SERIAL { ptr->best_mode = (uint8_t)g_S.pu_best_mode; ptr->best_dist = g_S.pu_best_dist; ptr->best_cost = g_S.pu_best_cost; ptr->valid = 1; }
     FCU_FOR_LANES {
       for (int i = lane; i < tu.nparts; i += 64) {
         cu->tr_idx[partOffset + i] = G->tmp_tr_idx[i]; cu->cbf[0][partOffset + i] = G->tmp_cbf[i]; cu->tskip[0][partOffset + i] = G->tmp_tskip[i];

@@ -340,6 +340,19 @@ int fcu_chain_set_decision(fcu_ctx *c, int chain, const fcu_decision_params *dp)
   return FCU_OK;
 }
 
+int fcu_pu_index(int depth, int nxn, int zidx) { return nxn ? 85 + zidx : (depth <= 0 ? 0 : depth == 1 ? 1 + (zidx >> 6) : depth == 2 ? 5 + (zidx >> 4) : 21 + (zidx >> 2)); }
+int fcu_chain_set_pu_trace(fcu_ctx *c, int chain, fcu_pu_trace *dev_trace)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_chain_set_pu_trace: bad argument");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_pu_trace: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  h.pu_trace = dev_trace;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, pu_trace), &h.pu_trace, sizeof(h.pu_trace), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
 int fcu_get_verify_counts(fcu_ctx *c, int first, int n, fcu_verify_counts *host_sum)
 {
   if (!c || !host_sum || first < 0 || n <= 0 || first + n > c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_get_verify_counts: bad argument");

@@ -85,9 +85,18 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
            "fcu_build_info", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full",
-           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer"]
+           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index"]
 
 SLICE_I, SLICE_P = 0, 1
+PUS_PER_CTU = 341
+PU_TRACE_DTYPE = np.dtype([("valid", np.uint8), ("best_mode", np.uint8), ("n_rmd", np.uint8), ("n_rd", np.uint8), ("rd_mode", np.uint8, (12,)),
+                           ("best_dist", np.uint32), ("pad", np.uint32), ("best_cost", np.float64), ("rmd_cost", np.float64, (8,))])   # fcu_pu_trace
+
+
+def pu_index(depth, nxn, zidx):
+    """fcu_pu_index: position of a PU inside its CTU's 341 records"""
+    return load_lib().fcu_pu_index(depth, nxn, zidx)
+
 REF_MARGIN = 80
 
 
@@ -147,6 +156,7 @@ def load_lib():
     lib.fcu_sao_update_rate.restype = None
     lib.fcu_sao_update_rate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.fcu_ldp_layer.argtypes = [C.c_int]
+    lib.fcu_chain_set_pu_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 
@@ -389,6 +399,20 @@ class CuEngine:
         v = VerifyCounts()
         self._chk(self.lib.fcu_get_verify_counts(self.h, first, n, C.byref(v)), "fcu_get_verify_counts")
         return np.array([[v.n[d][k] for k in range(6)] for d in range(4)], np.float64)
+
+    # -- per-PU record of the luma search (BASELINE configs[1])
+    def enable_pu_trace(self, chain, trace=None):
+        """Binds a device array of n_ctu x 341 fcu_pu_trace records to the chain (several slice chains of a picture may share
+        one).  Returns the uint8 tensor; pu_trace_array() turns it into a structured numpy array."""
+        torch = self.torch
+        if trace is None:
+            trace = torch.zeros(self.n_ctu * PUS_PER_CTU * PU_TRACE_DTYPE.itemsize, dtype=torch.uint8, device=torch.device("cuda", self.device))
+        self._chk(self.lib.fcu_chain_set_pu_trace(self.h, chain, trace.data_ptr()), "fcu_chain_set_pu_trace")
+        self._keep_obf[("pu_trace", chain)] = trace
+        return trace
+
+    def pu_trace_array(self, trace):
+        return trace.cpu().numpy().view(PU_TRACE_DTYPE).reshape(self.n_ctu, PUS_PER_CTU)
 
     # -- TComLoopFilter::loopFilterPic
     def deblock(self, chain=None, beta_offset_div2=0, tc_offset_div2=0, timed=False, stream=None, out=None, rec=None):

@@ -20,6 +20,8 @@
  *     (TEncCu.cpp:504-507,585-603,951-996,           fcu_get_verify_counts (g_iVerResult of the Verifying frame),
  *      1040,1143,1257,1446,1489-1497;                fcu_decision_switch (SetDecisionSwitch), fcu_frame_state
  *      tools_YS.cpp:686-695,968-986,1123-1154,1237)   (getCurrentState)
+ *   TEncSearch::estIntraPredLumaQT per-PU results  fcu_chain_set_pu_trace (BASELINE configs[1]: luma RDO artefact)
+ *     (TEncSearch.cpp:2178-2655)
  *   TComLoopFilter::loopFilterPic                  fcu_deblock (in-loop deblocking of the decided picture)
  *     (TComLoopFilter.cpp:130, TEncGOP.cpp:1160)
  *   TEncSampleAdaptiveOffset::SAOProcess           fcu_sao (statistics, per-CTU parameter decision, offset pass) +
@@ -219,6 +221,30 @@ int  fcu_sao(fcu_ctx *c, int n_pics, const fcu_sao_params *params, const uint8_t
 void fcu_sao_enabled(const double rate[3][8], int layer, int32_t enabled[3]);
 /* the bookkeeping at the end of decideBlkParams (:895-917) */
 void fcu_sao_update_rate(double rate[3][8], int layer, const int32_t off_count[3], int num_ctus);
+
+/* ---- per-PU record of the luma search (BASELINE configs[1]: intra-luma RDO, TEncSearch::estIntraPredLumaQT over the 35
+ * modes at all depths).  Exhaustive RDO visits every PU of the five layers of a CTU -- 1 + 4 + 16 + 64 PUs of 2Nx2N CUs at
+ * depth 0..3 and 256 PUs of NxN CUs at depth 3 = 341 -- and estIntraPredLumaQT (TEncSearch.cpp:2178-2655) leaves per PU: the
+ * RMD survivors with their SATD costs (CandCostList, :2289-2336), the candidate list after the MPM additions (:2407-2428),
+ * the winning mode, its luma distortion and RD cost after the full-RQT re-run (:2518-2586).  Optional side output of the
+ * ordinary decision: bind a device array of fcu_num_ctus() * FCU_PUS_PER_CTU records to a chain and every PU searched
+ * from then on is recorded at [ctu][fcu_pu_index]; PUs outside the picture or pruned by the fork's Testing state stay
+ * valid = 0.  The decisions themselves do not change. */
+#define FCU_PUS_PER_CTU 341
+typedef struct fcu_pu_trace {
+  uint8_t  valid;            /* 1 once the PU has been searched                                    */
+  uint8_t  best_mode;        /* luma intra direction of the PU                                     */
+  uint8_t  n_rmd;            /* RMD survivors (g_aucIntraModeNumFast: 8, 8, 3, 3, 3 for 4..64)     */
+  uint8_t  n_rd;             /* full-RD candidates after the MPM additions                         */
+  uint8_t  rd_mode[12];      /* the candidates in test order                                       */
+  uint32_t best_dist;        /* luma SSE of the winner                                             */
+  uint32_t pad;
+  double   best_cost;        /* its RD cost                                                        */
+  double   rmd_cost[8];      /* CandCostList of the survivors: SATD + sqrt(lambda) * mode bits     */
+} fcu_pu_trace;
+/* layer offsets 0 / 1 / 5 / 21 (2Nx2N CUs at depth 0..3) and 85 (NxN PUs); zidx = z-order index of the PU's first 4x4 partition */
+int  fcu_pu_index(int depth, int nxn, int zidx);
+int  fcu_chain_set_pu_trace(fcu_ctx *c, int chain, fcu_pu_trace *dev_trace);
 
 /* diagnostic: chains (one-wave workgroups of the engine kernel) the runtime keeps resident per compute unit */
 int  fcu_chains_per_cu(void);

@@ -169,6 +169,17 @@ void    hmo_deblock(HmoEnc *e, int betaOffsetDiv2, int tcOffsetDiv2);
 void    hmo_deblock_pic(const HmoCtu *pic, int width, int height, uint8_t *recY, uint8_t *recU, uint8_t *recV,
                         int betaOffsetDiv2, int tcOffsetDiv2);
 
+/* per-PU record of the luma search (BASELINE configs[1]; estIntraPredLumaQT, TEncSearch.cpp:2178-2655): same layout and
+ * indexing as include/fcu.h:fcu_pu_trace / fcu_pu_index.  buf = [num_ctus][341] records, or NULL to stop recording. */
+typedef struct {
+  uint8_t  valid, best_mode, n_rmd, n_rd;
+  uint8_t  rd_mode[12];
+  uint32_t best_dist, pad;
+  double   best_cost;
+  double   rmd_cost[8];
+} HmoPuTrace;
+void    hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf);
+
 /* sample adaptive offset (TEncSampleAdaptiveOffset::SAOProcess, TEncSampleAdaptiveOffset.cpp:257; TEncGOP.cpp:1434), hmo_sao.c */
 typedef struct { int mode, type, aux; int offset[32]; } HmoSaoOffset;      /* mode 0 off / 1 new / 2 merge; type: EO 0..3, BO 4 (merge: 0 left, 1 above); aux: band position */
 typedef struct { HmoSaoOffset c[3]; } HmoSaoBlk;

@@ -108,6 +108,7 @@ struct HmoEnc {
    * search code (oracle/ref/make_golden_search.py) or compare with what it returned (tests/test_golden_search.py) */
   void (*trace)(void *user, int event, int depth, int arg);
   void *trace_user;
+  HmoPuTrace *pu_trace;         /* optional per-PU record of the luma search (hmo_set_pu_trace) */
 };
 /* trace events: candidate about to be searched / searched (its results sit in temp[depth], reco_temp[depth], slot[depth][CI_TEMP_BEST]) */
 enum { HMO_EV_INTRA_BEGIN = 0, HMO_EV_INTRA_END = 1, HMO_EV_INTER_BEGIN = 2, HMO_EV_INTER_END = 3, HMO_EV_MERGE_BEGIN = 4, HMO_EV_MERGE_END = 5 };

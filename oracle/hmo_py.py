@@ -91,6 +91,7 @@ def load():
     lib.hmo_deblock_pic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.hmo_sao_picture.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
     lib.hmo_sao_stats.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hmo_set_pu_trace.argtypes = [C.c_void_p, C.c_void_p]
     lib.hmo_set_decision.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.hmo_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.hmo_decision_switch.argtypes = [C.c_void_p] * 5
@@ -105,6 +106,11 @@ def load():
     lib.hmo_test_last_luma_dist.argtypes = [C.c_void_p]
     lib.hmo_test_last_luma_dist.restype = C.c_uint32
     return lib
+
+
+PU_TRACE_DTYPE = np.dtype([("valid", np.uint8), ("best_mode", np.uint8), ("n_rmd", np.uint8), ("n_rd", np.uint8), ("rd_mode", np.uint8, (12,)),
+                           ("best_dist", np.uint32), ("pad", np.uint32), ("best_cost", np.float64), ("rmd_cost", np.float64, (8,))])   # = fcu_pu_trace
+PUS_PER_CTU = 341
 
 
 class Encoder:
@@ -195,6 +201,12 @@ class Encoder:
         v = np.zeros((4, 6), np.float64)
         self.lib.hmo_get_verify(self.h, v.ctypes.data)
         return v
+
+    def enable_pu_trace(self):
+        """per-PU record of the luma search (BASELINE configs[1]): structured array [n_ctu, 341], filled as CTUs are decided"""
+        self.pu_trace = np.zeros((self.n_ctu, PUS_PER_CTU), PU_TRACE_DTYPE)
+        self.lib.hmo_set_pu_trace(self.h, self.pu_trace.ctypes.data)
+        return self.pu_trace
 
     def deblock(self, beta_offset_div2=0, tc_offset_div2=0):
         """In-loop deblocking of the decided picture, in place on self.rec (TComLoopFilter::loopFilterPic)."""

@@ -535,6 +535,14 @@ static void est_intra_pred_luma_qt(HmoEnc *e, HmoCU *cu)
         if (!included) rdModeList[numModesForFullRD++] = preds[j];
       }
     }
+    HmoPuTrace *ptr = NULL;
+    if (e->pu_trace) {                                   /* candidate list and CandCostList as the RMD leaves them */
+      const int z = cu->zidx + partOffset, nRmd = hmo_rd_mode_num[log2 - 2];
+      ptr = e->pu_trace + (size_t)e->cur_ctu * 341 + (initTrDepth ? 85 + z : (d == 0 ? 0 : d == 1 ? 1 + (z >> 6) : d == 2 ? 5 + (z >> 4) : 21 + (z >> 2)));
+      ptr->n_rmd = (uint8_t)nRmd; ptr->n_rd = (uint8_t)numModesForFullRD; ptr->pad = 0;
+      for (int i = 0; i < 12; i++) ptr->rd_mode[i] = (uint8_t)(i < numModesForFullRD ? rdModeList[i] : 0);
+      for (int i = 0; i < 8; i++) ptr->rmd_cost[i] = i < nRmd ? candCost[i] : 0.0;
+    }
     /* ---- RDO over the candidates, no RQT split (TEncSearch.cpp:2447-2516) ---- */
     int bestPUMode = 0; uint32_t bestPUDist = 0; double bestPUCost = HMO_MAX_DOUBLE;
     for (int m = 0; m < numModesForFullRD; m++) {
@@ -565,6 +573,7 @@ static void est_intra_pred_luma_qt(HmoEnc *e, HmoCU *cu)
       }
     }
     overallDistY += bestPUDist;
+    if (ptr) { ptr->best_mode = (uint8_t)bestPUMode; ptr->best_dist = bestPUDist; ptr->best_cost = bestPUCost; ptr->valid = 1; }
     memcpy(cu->tr_idx + partOffset, e->tmp_tr_idx, (size_t)tu.nparts);
     for (int c = 0; c < 3; c++) { memcpy(cu->cbf[c] + partOffset, e->tmp_cbf[c], (size_t)tu.nparts); memcpy(cu->tskip[c] + partOffset, e->tmp_tskip[c], (size_t)tu.nparts); }
     if (pu != numPU - 1) {                               /* recon of the best PU for the next PU's prediction */
@@ -1028,6 +1037,7 @@ void hmo_decision_switch(const double *ver24, const double *th_skip, const doubl
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 /* test hooks (see hmo_int.h: trace) */
 void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
+void hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf) { e->pu_trace = buf; }
 const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }
 const HmoYuv *hmo_test_reco(const HmoEnc *e, int d, int best) { return best ? e->reco_best[d] : e->reco_temp[d]; }
 const HmoCabac *hmo_test_slot(const HmoEnc *e, int d, int ci) { return d < 0 ? &e->goon : &e->slot[d][ci]; }

@@ -51,6 +51,13 @@ class EmuEncoder:
         elif lam is not None:
             self.lib.fcu_emu_set_lambda(self.h, qp, float(lam))
 
+    def enable_pu_trace(self):
+        import hmo_py
+        self.pu_trace = np.zeros((self.n_ctu, hmo_py.PUS_PER_CTU), hmo_py.PU_TRACE_DTYPE)
+        self.lib.fcu_emu_set_pu_trace.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.fcu_emu_set_pu_trace(self.h, self.pu_trace.ctypes.data)
+        return self.pu_trace
+
     def compress_ctu(self, a):
         self.lib.fcu_emu_compress_ctu(self.h, a)
 

@@ -12,7 +12,8 @@ pass; never together with a trace flag), e.g.
   python tools/pmc_summary.py --config intra --chains 8160 --ctus 30 --timed 3 --out profiles/r02_pmc_summary.json \
          gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/pmc_tcc
 
-Per counter: the mean over the last `--timed` dispatches of the engine kernel (the timed steps of bench.py).  FETCH_SIZE
+A pass may also be given as a JSON file already reduced on the GPU box ({dispatch id: {counter: value}} of the engine
+kernel; the raw CSVs of a full bench run exceed what gpurun copies back).  Per counter: the mean over the last `--timed` dispatches of the engine kernel (the timed steps of bench.py).  FETCH_SIZE
 and WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950."""
 import argparse
 import csv
@@ -25,6 +26,12 @@ from collections import defaultdict
 
 def read_pass(d, kernel):
     per = defaultdict(lambda: defaultdict(float))          # dispatch -> counter -> value
+    if d.endswith(".json"):                                # a pass already reduced on the GPU box: {dispatch: {counter: value}} of the engine kernel
+        with open(d) as fh:
+            for k, v in json.load(fh).items():
+                for n, x in v.items():
+                    per[int(k)][n] += float(x)
+        return per
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
