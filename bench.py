@@ -10,8 +10,9 @@ row, and every chain is walked to the end of its slice.  A *step* advances every
 (compressCtu + encodeCtu replay per CTU) in one launch; chains are ordered longest (lowest QP) first.
 
 `--config ldp` (BASELINE.json configs[4]): 3840x2160 lowdelay_P, QP 32: picture 0 (intra) of every clip is decided,
-deblocked and padded untimed; the timed steps decide P-picture CTUs (merge / AMVP / full-search integer ME +-SearchRange
-with sub-sample refinement / inter RQT / intra fallback) against that reference.
+deblocked and padded untimed; the timed steps decide P-picture CTUs (merge / AMVP / integer ME +-SearchRange -- TZ search as in
+the reference cfg, `--fast-search 0` for the full search -- with sub-sample refinement / inter RQT / intra fallback) against
+that reference.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; every rank owns its own frames /
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--ctus-per-step", type=int, default=0, help="0 = walk the whole slice over warmup + steps launches (intra) / 2 (ldp)")
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--search-range", type=int, default=64)
+    ap.add_argument("--fast-search", type=int, default=1, help="lowdelay_P integer motion search: 1 = TZ search (FastSearch 1, the reference cfg's setting), 0 = full search")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep and the transfer measurement")
     ap.add_argument("--shard", choices=["frames", "slices"], default="frames")
@@ -199,6 +201,7 @@ def main():
         del pic0
         fp1 = pkg.engine.ldp_slice(32, 1)
         fp1.search_range = args.search_range
+        fp1.fast_search = args.fast_search
 
     def bind(ci):
         seed, qp, k = chain_list[ci]
@@ -274,7 +277,7 @@ def main():
         achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
-                f"merge + AMVP + full search +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
+                f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
                 f"one reference picture, TMVP off, AMP off" if ldp else
                 f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO (BASELINE configs[2])")
         res = {
@@ -307,7 +310,7 @@ def main():
                 if ldp:
                     _, q1, lam = hmo_py.ldp_slice(1, 32)
                     mk = lambda fr=fr: hmo_py.Encoder(*fr, q1, slice_ctus=sl if n_sl > 1 else 0, ref=[p.cpu().numpy() for p in _unpad(refs[seeds[0]], W, H)],
-                                                      lambda_override=lam, search_range=args.search_range)
+                                                      lambda_override=lam, search_range=args.search_range, fast_search=args.fast_search)
                 else:
                     mk = lambda fr=fr, qp=qp: hmo_py.Encoder(*fr, qp, slice_ctus=sl if n_sl > 1 else 0)
                 look = lambda a, ci=ci: eng.ctu_out(ci, a) if a < walked and switches is None else None

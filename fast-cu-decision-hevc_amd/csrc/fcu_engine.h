@@ -189,7 +189,7 @@ struct Params {
   double err_scale[2][4];     /* [luma/chroma][log2-2]   setErrScaleCoeff, TComTrQuant.cpp:3018-3040 */
   long long rd_factor[2];     /* sign-hiding rdFactor,   TComTrQuant.cpp:2444-2447 */
   /* P slices (BASELINE configs[4]) */
-  int search_range, fast_enc, had_me, fdm, max_merge_cand;
+  int search_range, fast_enc, had_me, fdm, max_merge_cand, fast_search;
   uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
 };
 
@@ -214,6 +214,7 @@ struct Chain {
   uint8_t sw_skip[4], sw_term[4];
   const int16_t *obf;
   double ver[4][6];
+  int int_mv[2];               /* m_integerMv2Nx2N[list 0][ref 0]: integer vector of the chain's last 2Nx2N motion search (TZ search start point) */
   fcu_pu_trace *pu_trace;      /* optional [n_ctu][FCU_PUS_PER_CTU] record of the luma search (fcu_chain_set_pu_trace) */
 };
 enum { DEC_TRAINING = 0, DEC_VERIFYING = 1, DEC_TESTING = 2 };
@@ -314,6 +315,8 @@ struct Shared {
       int iv_abs[6], iv_lsp[6], iv_top[6]; uint32_t iv_dist[6], iv_bits[6];   /* inter TU variants: Y, Y-ts, Cb, Cb-ts, Cr, Cr-ts */
       int it_abs[3], it_ts[3]; uint32_t it_dist[3]; /* chosen variant per component */
       double iq_cost[5]; uint32_t iq_bits[5], iq_dist[5], iq_zero;   /* xEstimateInterResidualQT accumulators per recursion level */
+      int16_t tz_x[16], tz_y[16]; uint8_t tz_pt[16], tz_d[16]; int tz_n;          /* TZ search: the positions of the round in flight (test order) */
+      uint32_t tz_best; int tz_bx, tz_by, tz_dist, tz_round, tz_point;               /* IntTZSearchStruct */
       int mrg_buf[5], best_is_skip, me_out[4];      /* xCheckRDCostMerge2Nx2N bookkeeping; motion_estimation results (mvx, mvy) */
     };
   };

@@ -287,6 +287,145 @@ FCU_DEV FCU_NOINLINE int estimate_mvp(const CuObj *cu, int ps, int pu)
  * g_S.acc[12] bits, g_S.acc[13] cost. */
 FCU_TABLE int8_t k_refine_h[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
 FCU_TABLE int8_t k_refine_q[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
+/* ---- xTZSearch (FastSearch 1), TEncSearch.cpp:3981-4180 with TZ_SEARCH_CONFIGURATION (:301-317).  The search is a sequence
+ * of rounds; a round tests a short list of positions in a fixed order and keeps the first strict improvement chain
+ * (xTZSearchHelp).  Lane 0 writes the round's list (the reference's order and border checks), the lanes take one position
+ * each (SAD over the PU + vector cost), and the wave's minimum of (cost << 32 | list index) is the position the reference's
+ * sequential scan would have ended on. */
+struct TzCtx { const uint8_t *org, *ref0; int rs, px, py, w, h, step, predx, predy; };
+FCU_DEV void tz_list_reset() { g_S.tz_n = 0; }
+FCU_DEV void tz_list_add(int x, int y, int point, int dist) { const int n = g_S.tz_n; if (n < 16) { g_S.tz_x[n] = (int16_t)x; g_S.tz_y[n] = (int16_t)y; g_S.tz_pt[n] = (uint8_t)point; g_S.tz_d[n] = (uint8_t)dist; g_S.tz_n = n + 1; } }
+/* runs the listed positions; list written by lane 0 beforehand */
+FCU_DEV void tz_run(const Params &P, const TzCtx &t)
+{
+  FCU_SERIAL g_S.me_best = ~0ull;
+  FCU_FOR_LANES {
+    unsigned long long key = ~0ull;
+    if (lane < g_S.tz_n) {
+      const int x = g_S.tz_x[lane], y = g_S.tz_y[lane];
+      uint32_t s = sad_block(t.org, t.ref0 + (t.py + y) * t.rs + t.px + x, t.rs, t.w, t.h, t.step);
+      if (t.step == 2) s <<= 1;
+      s += motion_cost(P, mv_bits(x, y, t.predx, t.predy, 2));
+      key = ((unsigned long long)s << 32) | (unsigned)lane;
+    }
+    FCU_WAVE_MIN64(&g_S.me_best, key);
+  }
+  FCU_SERIAL {
+    const uint32_t s = (uint32_t)(g_S.me_best >> 32); const int i = (int)(g_S.me_best & 0xffffffffull);
+    if (g_S.tz_n > 0 && s < g_S.tz_best) { g_S.tz_best = s; g_S.tz_bx = g_S.tz_x[i]; g_S.tz_by = g_S.tz_y[i]; g_S.tz_dist = g_S.tz_d[i]; g_S.tz_round = 0; g_S.tz_point = g_S.tz_pt[i]; }
+  }
+}
+/* xTZ8PointDiamondSearch, :625-805: the list of one diamond (lane 0) */
+FCU_DEV void tz_diamond_list(int ltx, int lty, int rbx, int rby, int sx, int sy, int d)
+{
+  const int top = sy - d, bot = sy + d, left = sx - d, right = sx + d;
+  tz_list_reset();
+  g_S.tz_round += 1;
+  if (d == 1) {
+    if (top >= lty) tz_list_add(sx, top, 2, d);
+    if (left >= ltx) tz_list_add(left, sy, 4, d);
+    if (right <= rbx) tz_list_add(right, sy, 5, d);
+    if (bot <= rby) tz_list_add(sx, bot, 7, d);
+  } else if (d <= 8) {
+    const int h = d >> 1, top2 = sy - h, bot2 = sy + h, left2 = sx - h, right2 = sx + h;
+    const int all = top >= lty && left >= ltx && right <= rbx && bot <= rby;
+    if (all || top >= lty) tz_list_add(sx, top, 2, d);
+    if (all || top2 >= lty) { if (all || left2 >= ltx) tz_list_add(left2, top2, 1, h); if (all || right2 <= rbx) tz_list_add(right2, top2, 3, h); }
+    if (all || left >= ltx) tz_list_add(left, sy, 4, d);
+    if (all || right <= rbx) tz_list_add(right, sy, 5, d);
+    if (all || bot2 <= rby) { if (all || left2 >= ltx) tz_list_add(left2, bot2, 6, h); if (all || right2 <= rbx) tz_list_add(right2, bot2, 8, h); }
+    if (all || bot <= rby) tz_list_add(sx, bot, 7, d);
+  } else {
+    const int q = d >> 2;
+    const int all = top >= lty && left >= ltx && right <= rbx && bot <= rby;
+    if (all || top >= lty) tz_list_add(sx, top, 0, d);
+    if (all || left >= ltx) tz_list_add(left, sy, 0, d);
+    if (all || right <= rbx) tz_list_add(right, sy, 0, d);
+    if (all || bot <= rby) tz_list_add(sx, bot, 0, d);
+    for (int i = 1; i < 4; i++) {
+      const int yt = top + q * i, yb = bot - q * i, xl = sx - q * i, xr = sx + q * i;
+      if (all || yt >= lty) { if (all || xl >= ltx) tz_list_add(xl, yt, 0, d); if (all || xr <= rbx) tz_list_add(xr, yt, 0, d); }
+      if (all || yb <= rby) { if (all || xl >= ltx) tz_list_add(xl, yb, 0, d); if (all || xr <= rbx) tz_list_add(xr, yb, 0, d); }
+    }
+  }
+}
+/* xTZ2PointSearch, :442-573 */
+FCU_DEV void tz_two_point_list(int ltx, int lty, int rbx, int rby)
+{
+  const int x = g_S.tz_bx, y = g_S.tz_by;
+  const int L = x - 1 >= ltx, R = x + 1 <= rbx, T = y - 1 >= lty, B = y + 1 <= rby;
+  tz_list_reset();
+  switch (g_S.tz_point) {
+  case 1: if (L) tz_list_add(x - 1, y, 0, 2); if (T) tz_list_add(x, y - 1, 0, 2); break;
+  case 2: if (T) { if (L) tz_list_add(x - 1, y - 1, 0, 2); if (R) tz_list_add(x + 1, y - 1, 0, 2); } break;
+  case 3: if (T) tz_list_add(x, y - 1, 0, 2); if (R) tz_list_add(x + 1, y, 0, 2); break;
+  case 4: if (L) { if (B) tz_list_add(x - 1, y + 1, 0, 2); if (T) tz_list_add(x - 1, y - 1, 0, 2); } break;
+  case 5: if (R) { if (T) tz_list_add(x + 1, y - 1, 0, 2); if (B) tz_list_add(x + 1, y + 1, 0, 2); } break;
+  case 6: if (L) tz_list_add(x - 1, y, 0, 2); if (B) tz_list_add(x, y + 1, 0, 2); break;
+  case 7: if (B) { if (L) tz_list_add(x - 1, y + 1, 0, 2); if (R) tz_list_add(x + 1, y + 1, 0, 2); } break;
+  case 8: if (R) tz_list_add(x + 1, y, 0, 2); if (B) tz_list_add(x, y + 1, 0, 2); break;
+  default: break;
+  }
+}
+/* the whole search; result in g_S.tz_bx / tz_by.  Diamonds use the window of the predictor (lt, rb); only the raster
+ * search uses the window re-centred on the best start point when a 2Nx2N integer vector was offered (:4023-4037). */
+FCU_DEV void tz_search(const Params &P, const CuObj *cu, const TzCtx &t, int ltx, int lty, int rbx, int rby, int useIntMv, int imx, int imy)
+{
+  const int range = P.search_range, raster = 5;
+  int rltx = ltx, rlty = lty, rrbx = rbx, rrby = rby;
+  int stx = t.predx, sty = t.predy; clip_mv(P, cu, stx, sty); stx >>= 2; sty >>= 2;
+  int mx = imx << 2, my = imy << 2; clip_mv(P, cu, mx, my); mx >>= 2; my >>= 2;
+  FCU_SERIAL {
+    g_S.tz_best = 0xffffffffu; g_S.tz_bx = g_S.tz_by = 0; g_S.tz_dist = 0; g_S.tz_round = 0; g_S.tz_point = 0;
+    tz_list_reset(); tz_list_add(stx, sty, 0, 0); tz_list_add(0, 0, 0, 0);               /* predictor, zero vector */
+    if (useIntMv) tz_list_add(mx, my, 0, 0);
+  }
+  tz_run(P, t);
+  if (useIntMv) {
+    int cx = FCU_UNI(g_S.tz_bx) << 2, cy = FCU_UNI(g_S.tz_by) << 2; clip_mv(P, cu, cx, cy);
+    rltx = cx - (range << 2); rlty = cy - (range << 2); rrbx = cx + (range << 2); rrby = cy + (range << 2);
+    clip_mv(P, cu, rltx, rlty); clip_mv(P, cu, rrbx, rrby);
+    rltx >>= 2; rlty >>= 2; rrbx >>= 2; rrby >>= 2;
+  }
+  int sx = FCU_UNI(g_S.tz_bx), sy = FCU_UNI(g_S.tz_by);
+  for (int d = 1; d <= range; d *= 2) {                        /* first search: stops three rounds after the last improvement */
+    FCU_SERIAL tz_diamond_list(ltx, lty, rbx, rby, sx, sy, d);
+    tz_run(P, t);
+    if (FCU_UNI(g_S.tz_round) >= 3) break;
+  }
+  if (FCU_UNI(g_S.tz_dist) == 1) { FCU_SERIAL { g_S.tz_dist = 0; tz_two_point_list(ltx, lty, rbx, rby); } tz_run(P, t); }
+  if (FCU_UNI(g_S.tz_dist) > raster) {                         /* raster search, step 5: one position per lane, raster order wins ties */
+    const int nx = (rrbx - rltx) / raster + 1, ny = (rrby - rlty) / raster + 1;
+    FCU_SERIAL { g_S.tz_dist = raster; g_S.me_best = ~0ull; }
+    FCU_FOR_LANES {
+      unsigned long long best = ~0ull;
+      for (int p = lane; p < nx * ny; p += 64) {
+        const int yy = p / nx, xx = p - yy * nx, x = rltx + xx * raster, y = rlty + yy * raster;
+        uint32_t s = sad_block(t.org, t.ref0 + (t.py + y) * t.rs + t.px + x, t.rs, t.w, t.h, t.step);
+        if (t.step == 2) s <<= 1;
+        s += motion_cost(P, mv_bits(x, y, t.predx, t.predy, 2));
+        const unsigned long long key = ((unsigned long long)s << 32) | (unsigned)p;
+        if (key < best) best = key;
+      }
+      FCU_WAVE_MIN64(&g_S.me_best, best);
+    }
+    FCU_SERIAL {
+      const uint32_t s = (uint32_t)(g_S.me_best >> 32); const int p = (int)(g_S.me_best & 0xffffffffull);
+      if (nx > 0 && ny > 0 && s < g_S.tz_best) { g_S.tz_best = s; g_S.tz_bx = rltx + (p % nx) * raster; g_S.tz_by = rlty + (p / nx) * raster; g_S.tz_dist = raster; g_S.tz_round = 0; g_S.tz_point = 0; }
+    }
+  }
+  while (FCU_UNI(g_S.tz_dist) > 0) {                           /* star refinement */
+    sx = FCU_UNI(g_S.tz_bx); sy = FCU_UNI(g_S.tz_by);
+    FCU_SERIAL { g_S.tz_dist = 0; g_S.tz_point = 0; }
+    for (int d = 1; d < range + 1; d *= 2) { FCU_SERIAL tz_diamond_list(ltx, lty, rbx, rby, sx, sy, d); tz_run(P, t); }
+    if (FCU_UNI(g_S.tz_dist) == 1) {
+      const int two = FCU_UNI(g_S.tz_point) != 0;
+      FCU_SERIAL { g_S.tz_dist = 0; if (two) tz_two_point_list(ltx, lty, rbx, rby); }
+      if (two) tz_run(P, t);
+    }
+  }
+}
+
 FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int predx, int predy, uint32_t bitsIn)
 {
   const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); predx = FCU_UNI(predx); predy = FCU_UNI(predy); bitsIn = FCU_UNI(bitsIn);
@@ -301,6 +440,14 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   clip_mv(P, cu, ltx, lty); clip_mv(P, cu, rbx, rby);
   ltx >>= 2; lty >>= 2; rbx >>= 2; rby >>= 2;
   const int nx = rbx - ltx + 1, ny = rby - lty + 1, step = (P.fast_enc && g.h > 8) ? 2 : 1;
+  int bx, by;
+  if (P.fast_search) {                                       /* xPatternSearchFast -> xTZSearch; m_integerMv2Nx2N, TEncSearch.cpp:3822-3833 */
+    TzCtx t; t.org = org; t.ref0 = ref0; t.rs = rs; t.px = px; t.py = py; t.w = g.w; t.h = g.h; t.step = step; t.predx = predx; t.predy = predy;
+    const int usePred = ps != SIZE_2Nx2N || cu->depth_cu != 0;
+    tz_search(P, cu, t, ltx, lty, rbx, rby, usePred, FCU_UNI(E.C->int_mv[0]), FCU_UNI(E.C->int_mv[1]));
+    bx = FCU_UNI(g_S.tz_bx); by = FCU_UNI(g_S.tz_by);
+    if (ps == SIZE_2Nx2N) FCU_SERIAL { E.C->int_mv[0] = bx; E.C->int_mv[1] = by; }
+  } else {
   FCU_SERIAL g_S.me_best = ~0ull;
   FCU_FOR_LANES {                                            /* one candidate position per lane */
     unsigned long long best = ~0ull;
@@ -315,7 +462,8 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
     FCU_WAVE_MIN64(&g_S.me_best, best);
   }
   const unsigned bp = (unsigned)FCU_UNI((int)(unsigned)(g_S.me_best & 0xffffffffull));
-  const int bx = ltx + (int)(bp % (unsigned)nx), by = lty + (int)(bp / (unsigned)nx);
+  bx = ltx + (int)(bp % (unsigned)nx); by = lty + (int)(bp / (unsigned)nx);
+  }
   /* half-sample round, then quarter-sample round around the winner */
   int hx = 0, hy = 0, qx = 0, qy = 0; uint32_t bestD = 0;
   for (int round = 0; round < 2; round++) {

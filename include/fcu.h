@@ -86,11 +86,12 @@ typedef struct fcu_frame_params {
   double lambda, sqrt_lambda, chroma_weight, rdoq_lambda[3];
   /* P slices (lowdelay_P, BASELINE configs[4]); all 0 in an I slice */
   int slice_type;                /* FCU_SLICE_I / FCU_SLICE_P: a P chain needs fcu_chain_set_reference                   */
-  int search_range;              /* SearchRange in integer samples (64); the search is HM's full search (FastSearch 0)  */
+  int search_range;              /* SearchRange in integer samples (64)                                                 */
   int fast_enc;                  /* FEN: every other row in the integer-search SAD of blocks taller than 8              */
   int hadamard_me;               /* HadamardME: SATD in the sub-sample refinement and the merge estimation              */
   int fast_merge_decision;       /* FDM                                                                                  */
   int max_merge_cand;            /* MaxNumMergeCand (5)                                                                  */
+  int fast_search;               /* FastSearch: 0 = full search (xPatternSearch), 1 = TZ search (xTZSearch, HM's cfg default) */
 } fcu_frame_params;
 enum { FCU_SLICE_I = 0, FCU_SLICE_P = 1 };
 #define FCU_REF_MARGIN_LUMA 80   /* border of a padded reference plane: g_uiMaxCUWidth + 16 (TComPic::create); chroma: 40 */

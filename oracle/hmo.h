@@ -179,6 +179,7 @@ typedef struct {
   double   rmd_cost[8];
 } HmoPuTrace;
 void    hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf);
+void    hmo_test_int_mv(const HmoEnc *e, int *xy);          /* m_integerMv2Nx2N as the search holds it now (TZ search state) */
 
 /* sample adaptive offset (TEncSampleAdaptiveOffset::SAOProcess, TEncSampleAdaptiveOffset.cpp:257; TEncGOP.cpp:1434), hmo_sao.c */
 typedef struct { int mode, type, aux; int offset[32]; } HmoSaoOffset;      /* mode 0 off / 1 new / 2 merge; type: EO 0..3, BO 4 (merge: 0 left, 1 above); aux: band position */

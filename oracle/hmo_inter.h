@@ -244,26 +244,144 @@ static HmoMv estimate_mvp(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv cand
 static const int8_t k_refine_h[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
 static const int8_t k_refine_q[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
 
+/* ---- xTZSearch (FastSearch 1), TEncSearch.cpp:3981-4180, with TZ_SEARCH_CONFIGURATION (:301-317): zero-vector test on,
+ * other predictors off, diamond first search that stops three rounds after the last improvement (FASTME_SMOOTHER_MV),
+ * raster search with step 5 when the best distance is larger, star refinement with diamonds, no raster refinement. */
+typedef struct { uint32_t best; int bx, by, dist, round, point; const uint8_t *org; int px, py, w, h, sub; HmoMv pred; } HmoTz;
+/* xTZSearchHelp, :336-441 (not the selective variant) */
+static void tz_help(HmoEnc *e, HmoTz *s, int x, int y, int point, int dist)
+{
+  uint32_t sad = sad_ref(e, s->org, 64, s->px + x, s->py + y, s->w, s->h, s->sub) + motion_cost(e, mv_bits(x, y, s->pred, 2));
+  e->n_sad++;
+  if (sad < s->best) { s->best = sad; s->bx = x; s->by = y; s->dist = dist; s->round = 0; s->point = point; }
+}
+/* xTZ2PointSearch, :442-573: the two untested neighbours of the best point of a distance-1 round */
+static void tz_two_point(HmoEnc *e, HmoTz *s, HmoMv lt, HmoMv rb)
+{
+  const int x = s->bx, y = s->by;
+  const int L = x - 1 >= lt.x, R = x + 1 <= rb.x, T = y - 1 >= lt.y, B = y + 1 <= rb.y;
+  switch (s->point) {
+  case 1: if (L) tz_help(e, s, x - 1, y, 0, 2); if (T) tz_help(e, s, x, y - 1, 0, 2); break;
+  case 2: if (T) { if (L) tz_help(e, s, x - 1, y - 1, 0, 2); if (R) tz_help(e, s, x + 1, y - 1, 0, 2); } break;
+  case 3: if (T) tz_help(e, s, x, y - 1, 0, 2); if (R) tz_help(e, s, x + 1, y, 0, 2); break;
+  case 4: if (L) { if (B) tz_help(e, s, x - 1, y + 1, 0, 2); if (T) tz_help(e, s, x - 1, y - 1, 0, 2); } break;
+  case 5: if (R) { if (T) tz_help(e, s, x + 1, y - 1, 0, 2); if (B) tz_help(e, s, x + 1, y + 1, 0, 2); } break;
+  case 6: if (L) tz_help(e, s, x - 1, y, 0, 2); if (B) tz_help(e, s, x, y + 1, 0, 2); break;
+  case 7: if (B) { if (L) tz_help(e, s, x - 1, y + 1, 0, 2); if (R) tz_help(e, s, x + 1, y + 1, 0, 2); } break;
+  case 8: if (R) tz_help(e, s, x + 1, y, 0, 2); if (B) tz_help(e, s, x, y + 1, 0, 2); break;
+  default: break;
+  }
+}
+/* xTZ8PointDiamondSearch, :625-805 */
+static void tz_diamond(HmoEnc *e, HmoTz *s, HmoMv lt, HmoMv rb, int sx, int sy, int d)
+{
+  const int top = sy - d, bot = sy + d, left = sx - d, right = sx + d;
+  s->round += 1;
+  if (d == 1) {
+    if (top >= lt.y) tz_help(e, s, sx, top, 2, d);
+    if (left >= lt.x) tz_help(e, s, left, sy, 4, d);
+    if (right <= rb.x) tz_help(e, s, right, sy, 5, d);
+    if (bot <= rb.y) tz_help(e, s, sx, bot, 7, d);
+  } else if (d <= 8) {
+    const int h = d >> 1, top2 = sy - h, bot2 = sy + h, left2 = sx - h, right2 = sx + h;
+    if (top >= lt.y && left >= lt.x && right <= rb.x && bot <= rb.y) {
+      tz_help(e, s, sx, top, 2, d); tz_help(e, s, left2, top2, 1, h); tz_help(e, s, right2, top2, 3, h);
+      tz_help(e, s, left, sy, 4, d); tz_help(e, s, right, sy, 5, d);
+      tz_help(e, s, left2, bot2, 6, h); tz_help(e, s, right2, bot2, 8, h); tz_help(e, s, sx, bot, 7, d);
+    } else {
+      if (top >= lt.y) tz_help(e, s, sx, top, 2, d);
+      if (top2 >= lt.y) { if (left2 >= lt.x) tz_help(e, s, left2, top2, 1, h); if (right2 <= rb.x) tz_help(e, s, right2, top2, 3, h); }
+      if (left >= lt.x) tz_help(e, s, left, sy, 4, d);
+      if (right <= rb.x) tz_help(e, s, right, sy, 5, d);
+      if (bot2 <= rb.y) { if (left2 >= lt.x) tz_help(e, s, left2, bot2, 6, h); if (right2 <= rb.x) tz_help(e, s, right2, bot2, 8, h); }
+      if (bot <= rb.y) tz_help(e, s, sx, bot, 7, d);
+    }
+  } else {
+    const int q = d >> 2;
+    if (top >= lt.y && left >= lt.x && right <= rb.x && bot <= rb.y) {
+      tz_help(e, s, sx, top, 0, d); tz_help(e, s, left, sy, 0, d); tz_help(e, s, right, sy, 0, d); tz_help(e, s, sx, bot, 0, d);
+      for (int i = 1; i < 4; i++) {
+        const int yt = top + q * i, yb = bot - q * i, xl = sx - q * i, xr = sx + q * i;
+        tz_help(e, s, xl, yt, 0, d); tz_help(e, s, xr, yt, 0, d); tz_help(e, s, xl, yb, 0, d); tz_help(e, s, xr, yb, 0, d);
+      }
+    } else {
+      if (top >= lt.y) tz_help(e, s, sx, top, 0, d);
+      if (left >= lt.x) tz_help(e, s, left, sy, 0, d);
+      if (right <= rb.x) tz_help(e, s, right, sy, 0, d);
+      if (bot <= rb.y) tz_help(e, s, sx, bot, 0, d);
+      for (int i = 1; i < 4; i++) {
+        const int yt = top + q * i, yb = bot - q * i, xl = sx - q * i, xr = sx + q * i;
+        if (yt >= lt.y) { if (xl >= lt.x) tz_help(e, s, xl, yt, 0, d); if (xr <= rb.x) tz_help(e, s, xr, yt, 0, d); }
+        if (yb <= rb.y) { if (xl >= lt.x) tz_help(e, s, xl, yb, 0, d); if (xr <= rb.x) tz_help(e, s, xr, yb, 0, d); }
+      }
+    }
+  }
+}
+/* xSetSearchRange, :3865-3884 */
+static void set_search_range(const HmoEnc *e, const HmoCU *cu, HmoMv pred, int rng, HmoMv *lt, HmoMv *rb)
+{
+  HmoMv c = clip_mv(e, cu, pred);
+  lt->x = c.x - (rng << 2); lt->y = c.y - (rng << 2); rb->x = c.x + (rng << 2); rb->y = c.y + (rng << 2);
+  *lt = clip_mv(e, cu, *lt); *rb = clip_mv(e, cu, *rb);
+  lt->x >>= 2; lt->y >>= 2; rb->x >>= 2; rb->y >>= 2;
+}
+static void tz_search(HmoEnc *e, const HmoCU *cu, HmoTz *s, HmoMv lt, HmoMv rb, const HmoMv *intMv2Nx2N, int *outX, int *outY)
+{
+  const int range = e->p.search_range, raster = 5;
+  HmoMv rlt = lt, rrb = rb;                                   /* the raster search may use a window re-centred below */
+  HmoMv st = clip_mv(e, cu, s->pred); st.x >>= 2; st.y >>= 2;
+  s->best = HMO_MAX_UINT; s->bx = s->by = 0; s->dist = 0; s->round = 0; s->point = 0;
+  tz_help(e, s, st.x, st.y, 0, 0);
+  tz_help(e, s, 0, 0, 0, 0);                                  /* bTestZeroVector */
+  if (intMv2Nx2N) {
+    HmoMv m; m.x = intMv2Nx2N->x << 2; m.y = intMv2Nx2N->y << 2; m = clip_mv(e, cu, m); m.x >>= 2; m.y >>= 2;
+    tz_help(e, s, m.x, m.y, 0, 0);
+    HmoMv cur; cur.x = s->bx << 2; cur.y = s->by << 2;
+    set_search_range(e, cu, cur, range, &rlt, &rrb);
+  }
+  int sx = s->bx, sy = s->by;
+  for (int d = 1; d <= range; d *= 2) {                       /* first search */
+    tz_diamond(e, s, lt, rb, sx, sy, d);
+    if (s->round >= 3) break;                                 /* bFirstSearchStop, uiFirstSearchRounds */
+  }
+  if (s->dist == 1) { s->dist = 0; tz_two_point(e, s, lt, rb); }
+  if (s->dist > raster) {                                     /* raster search */
+    s->dist = raster;
+    for (int y = rlt.y; y <= rrb.y; y += raster) for (int x = rlt.x; x <= rrb.x; x += raster) tz_help(e, s, x, y, 0, raster);
+  }
+  while (s->dist > 0) {                                       /* star refinement */
+    sx = s->bx; sy = s->by; s->dist = 0; s->point = 0;
+    for (int d = 1; d < range + 1; d *= 2) tz_diamond(e, s, lt, rb, sx, sy, d);
+    if (s->dist == 1) { s->dist = 0; if (s->point != 0) tz_two_point(e, s, lt, rb); }
+  }
+  *outX = s->bx; *outY = s->by;
+}
+
 static void motion_estimation(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv pred, HmoMv *mvOut, uint32_t *bits, uint32_t *cost)
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
   const uint8_t *org = e->org_yuv[cu->depth_cu]->y + oy * 64 + ox;
   const int px = cu->x + ox, py = cu->y + oy, rng = e->p.search_range;
-  /* xSetSearchRange */
-  HmoMv c = clip_mv(e, cu, pred), lt, rb;
-  lt.x = c.x - (rng << 2); lt.y = c.y - (rng << 2); rb.x = c.x + (rng << 2); rb.y = c.y + (rng << 2);
-  lt = clip_mv(e, cu, lt); rb = clip_mv(e, cu, rb);
-  lt.x >>= 2; lt.y >>= 2; rb.x >>= 2; rb.y >>= 2;
-  /* xPatternSearch, cost scale 2 */
+  HmoMv lt, rb;
+  set_search_range(e, cu, pred, rng, &lt, &rb);
   const int subShift = (e->p.fast_enc && h > 8) ? 1 : 0;
-  uint32_t best = HMO_MAX_UINT; int bx = 0, by = 0;
-  for (int y = lt.y; y <= rb.y; y++)
-    for (int x = lt.x; x <= rb.x; x++) {
-      uint32_t s = sad_ref(e, org, 64, px + x, py + y, w, h, subShift);
-      s += motion_cost(e, mv_bits(x, y, pred, 2));
-      if (s < best) { best = s; bx = x; by = y; }
-    }
-  e->n_sad += (uint64_t)(rb.y - lt.y + 1) * (uint64_t)(rb.x - lt.x + 1);
+  int bx = 0, by = 0;
+  if (!e->p.fast_search) {                                   /* xPatternSearch, cost scale 2 */
+    uint32_t best = HMO_MAX_UINT;
+    for (int y = lt.y; y <= rb.y; y++)
+      for (int x = lt.x; x <= rb.x; x++) {
+        uint32_t s = sad_ref(e, org, 64, px + x, py + y, w, h, subShift);
+        s += motion_cost(e, mv_bits(x, y, pred, 2));
+        if (s < best) { best = s; bx = x; by = y; }
+      }
+    e->n_sad += (uint64_t)(rb.y - lt.y + 1) * (uint64_t)(rb.x - lt.x + 1);
+  } else {                                                   /* xPatternSearchFast -> xTZSearch; m_integerMv2Nx2N, TEncSearch.cpp:3822-3833 */
+    HmoTz s; s.org = org; s.px = px; s.py = py; s.w = w; s.h = h; s.sub = subShift; s.pred = pred;
+    const int usePred = partSize != HMO_SIZE_2Nx2N || cu->depth_cu != 0;
+    HmoMv imv; imv.x = e->int_mv_2nx2n.x; imv.y = e->int_mv_2nx2n.y;
+    tz_search(e, cu, &s, lt, rb, usePred ? &imv : NULL, &bx, &by);
+    if (partSize == HMO_SIZE_2Nx2N) { e->int_mv_2nx2n.x = bx; e->int_mv_2nx2n.y = by; }
+  }
   /* xPatternSearchFracDIF: half positions around (bx, by), cost scale 1; then quarter positions, cost scale 0 */
   uint8_t blk[64 * 64];
   uint32_t bestD = HMO_MAX_UINT; int bh = 0;

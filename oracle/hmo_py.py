@@ -202,6 +202,12 @@ class Encoder:
         self.lib.hmo_get_verify(self.h, v.ctypes.data)
         return v
 
+    def test_int_mv(self):
+        xy = (C.c_int * 2)()
+        self.lib.hmo_test_int_mv.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.hmo_test_int_mv(self.h, xy)
+        return int(xy[0]), int(xy[1])
+
     def enable_pu_trace(self):
         """per-PU record of the luma search (BASELINE configs[1]): structured array [n_ctu, 341], filled as CTUs are decided"""
         self.pu_trace = np.zeros((self.n_ctu, PUS_PER_CTU), PU_TRACE_DTYPE)

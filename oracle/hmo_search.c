@@ -1038,6 +1038,7 @@ const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 /* test hooks (see hmo_int.h: trace) */
 void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
 void hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf) { e->pu_trace = buf; }
+void hmo_test_int_mv(const HmoEnc *e, int *xy) { xy[0] = e->int_mv_2nx2n.x; xy[1] = e->int_mv_2nx2n.y; }
 const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }
 const HmoYuv *hmo_test_reco(const HmoEnc *e, int d, int best) { return best ? e->reco_best[d] : e->reco_temp[d]; }
 const HmoCabac *hmo_test_slot(const HmoEnc *e, int d, int ci) { return d < 0 ? &e->goon : &e->slot[d][ci]; }

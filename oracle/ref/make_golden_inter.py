@@ -13,7 +13,8 @@ ref_inter_cu, ref_intra_cu = the bodies of TEncCu::xCheckRDCostMerge2Nx2N / xChe
 fixture stores what THE REFERENCE returned per candidate (distortion, bits, cost, motion of the first and last partition,
 CRC-32s of all motion / mode arrays, of the TU tree, coefficients, reconstruction and coder state) and the CRC-32 of each
 deblocked P picture.  tests/test_golden_inter.py re-runs the oracle and compares candidate by candidate.
-Configuration: DESIGN.md 3e (one reference picture, TMVP off, AMP off, full search, FEN, FDM, HadamardME).
+Configuration: DESIGN.md 3e (one reference picture, TMVP off, AMP off, full search or -- the tz_* cases -- TZ search, FEN, FDM,
+HadamardME).
 
 Run in the build container only:  python oracle/ref/make_golden_inter.py [case]
 """
@@ -35,7 +36,10 @@ CASES = {      # name: (generator, width, height, base QP, seed, pictures, searc
     "textured_qp32": ("textured", 192, 128, 32, 7, 3, 64),       # SearchRange 64 (the configuration default)
     "mixed_qp27": ("mixed", 136, 72, 27, 31, 4, 8),              # partial CTUs, intra CUs inside P pictures
     "textured_qp37": ("textured", 128, 64, 37, 9, 5, 32),        # all four GOP positions
+    "tz_textured_qp32": ("textured", 192, 128, 32, 7, 3, 64),    # FastSearch 1 (TZ search), SearchRange 64: raster search, star refinement
+    "tz_mixed_qp27": ("mixed", 136, 72, 27, 31, 3, 16),          # FastSearch 1, small window, partial CTUs
 }
+FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1}        # HM's FastSearch of a case (default 0 = full search)
 
 
 def run_case(case, ref_factory, on_picture):
@@ -57,7 +61,7 @@ def run_case(case, ref_factory, on_picture):
             enc.compress_frame()
             out.append((None, None))
         else:
-            enc = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+            enc = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
             ref = ref_factory(poc, f, qp, lam, prev, sr) if ref_factory else None
             irec, mrec, bad = [], [], [0]
 
@@ -104,7 +108,7 @@ def one(case):
     dbk, total_bad = {}, [0]
 
     def ref_factory(poc, f, qp, lam, prev, sr):
-        r = st.RefSearch(w, h, qp, f, search_range=sr)
+        r = st.RefSearch(w, h, qp, f, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
         r.setup_p(prev, lam)
         return r
 

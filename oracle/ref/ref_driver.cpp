@@ -576,6 +576,10 @@ int ref_merge_cu(int ctu, int zidx, int depth, int cand, int noResidual, RefCuOu
   return numValid;
 }
 
+/* TZ search (FastSearch 1) starts non-2Nx2N / deeper searches from the integer vector of the last 2Nx2N search
+ * (m_integerMv2Nx2N, TEncSearch.cpp:3822-3833): encoder state that the caller carries over from its own search */
+void ref_set_int_mv(int x, int y) { g_search->m_integerMv2Nx2N[0][0].set(x, y); }
+
 /* ---- sample adaptive offset: the reference's own TEncSampleAdaptiveOffset on the picture held by the driver -------------
  * PicYuvOrg / PicYuvRec (the deblocked picture) are loaded with ref_set_org / ref_set_rec.  The call sequence is TEncGOP's
  * (TEncGOP.cpp:1427-1441): initRDOCabacCoder(go-on coder, slice) then SAOProcess(pic, sliceEnabled, slice lambdas, SaoCtuBoundary

@@ -33,12 +33,12 @@ void *fcu_emu_create(int width, int height, int qp, int slice_ctus, int tools, c
 }
 /* P picture: lambda of the slice (fcu_ldp_slice on the host), search range, and the padded reference planes
  * (luma margin FCU_REF_MARGIN, pointers to the first byte of each padded plane) */
-void fcu_emu_set_p(void *h, int qp, double lambda, int search_range, const uint8_t *py, const uint8_t *pu, const uint8_t *pv)
+void fcu_emu_set_p(void *h, int qp, double lambda, int search_range, int fast_search, const uint8_t *py, const uint8_t *pu, const uint8_t *pv)
 {
   EmuChain *e = (EmuChain *)h;
   const int width = e->c.p.width, height = e->c.p.height;
   fcu_frame_params fp; default_frame_params(fp, qp);
-  fp.slice_ctus = e->c.p.slice_ctus; fp.slice_type = FCU_SLICE_P; fp.lambda = lambda; fp.search_range = search_range;
+  fp.slice_ctus = e->c.p.slice_ctus; fp.slice_type = FCU_SLICE_P; fp.lambda = lambda; fp.search_range = search_range; fp.fast_search = fast_search;
   fill_params(e->c.p, width, height, fp);
   const int m = FCU_REF_MARGIN, sy = width + 2 * m, sc = width / 2 + m;
   e->c.ref_stride[0] = sy; e->c.ref_stride[1] = e->c.ref_stride[2] = sc;

@@ -20,7 +20,7 @@ def load():
     lib.fcu_emu_get_verify.argtypes = [C.c_void_p, C.c_void_p]
     lib.fcu_emu_tu_trials.restype = C.c_ulonglong
     lib.fcu_emu_tu_trials.argtypes = [C.c_void_p]
-    lib.fcu_emu_set_p.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fcu_emu_set_p.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcu_emu_set_lambda.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.fcu_emu_get_state_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -35,7 +35,7 @@ def pad_planes(planes):
 
 
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0):
         """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda)"""
         self.lib = load()
         h, w = Y.shape
@@ -47,7 +47,7 @@ class EmuEncoder:
                                          *[a.ctypes.data for a in self.rec], C.addressof(self.out))
         if ref is not None:
             self.pad = pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in ref])
-            self.lib.fcu_emu_set_p(self.h, qp, float(lam), search_range, *[a.ctypes.data for a in self.pad])
+            self.lib.fcu_emu_set_p(self.h, qp, float(lam), search_range, fast_search, *[a.ctypes.data for a in self.pad])
         elif lam is not None:
             self.lib.fcu_emu_set_lambda(self.h, qp, float(lam))
 

@@ -137,14 +137,15 @@ class RefCuOut(C.Structure):
 class RefSearch:
     """The reference's TEncSearch behind ref_driver.cpp, fed with oracle states."""
 
-    def __init__(self, w, h, qp, org, search_range=64):
+    def __init__(self, w, h, qp, org, search_range=64, fast_search=0):
         self.L = L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhmleaf.so"))
         L.ref_coder_get.restype = C.c_ulonglong
         L.ref_coder_set.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ulonglong]
         L.ref_coder_get.argtypes = [C.c_int, C.c_int, C.c_void_p]
         self.w, self.h, self.qp = w, h, qp
         self.n_ctu = L.ref_setup(w, h, qp)
-        assert L.ref_search_setup(search_range, 0, 1, 1, 1) == 0
+        assert L.ref_search_setup(search_range, fast_search, 1, 1, 1) == 0
+        self.fast_search = fast_search
         self.is_p = False
         for c in range(3):
             L.ref_set_org(c, np.ascontiguousarray(org[c]).ctypes.data_as(C.c_void_p))
@@ -204,6 +205,8 @@ class RefSearch:
         for a in range(max(0, cur - self.w_ctu - 1), cur + 1):
             c = enc.ctu_arrays(a)
             L.ref_set_ctu_inter(a, vp(c["skip"]), vp(c["inter_dir"]), vp(c["merge_flag"]), vp(c["mv"]), vp(c["ref_idx"]))
+        if self.fast_search:                                    # TZ search state carried from the oracle's own search
+            L.ref_set_int_mv(*enc.test_int_mv())
 
     def deblock(self, enc, beta=0, tc=0):
         """the reference's loopFilterPic on the oracle's decided picture (its arrays + un-filtered reconstruction)"""

@@ -22,8 +22,9 @@ def _same_ctu(got, want, tag):
             assert v == got[k], f"{tag}: {k}: engine {got[k]} oracle {v}"
 
 
-@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr", [("mixed", 136, 72, 27, 3, 8), ("textured", 192, 128, 32, 3, 16), ("smooth", 128, 64, 37, 5, 64)])
-def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr):
+@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,fast", [("mixed", 136, 72, 27, 3, 8, 0), ("textured", 192, 128, 32, 3, 16, 0), ("smooth", 128, 64, 37, 5, 64, 0),
+                                                               ("mixed", 136, 72, 27, 3, 16, 1), ("textured", 192, 128, 32, 3, 64, 1)])     # fast = 1: TZ search (FastSearch 1)
+def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast):
     """compressCtu-shaped calls: every CTU of every picture of a short lowdelay_P clip, CABAC state after every CTU."""
     eng = pkg.CuEngine(w, h, max_chains=1)
     prev, prev_pad = None, None
@@ -31,10 +32,11 @@ def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr):
         f = st.moving_frame(pkg.synth, gen, w, h, 5, poc)
         fp = pkg.engine.ldp_slice(base_qp, poc)
         fp.search_range = sr
+        fp.fast_search = fast
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
         assert fp.qp == qp and fp.lambda_ == lam and fp.slice_type == (0 if poc == 0 else 1)
         eng.init_chain(0, f, fp.qp, params=fp, ref=prev_pad)
-        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=fast)
         for a in range(eng.n_ctu):
             got = eng.compress_ctu(0, a)
             ref.compress_ctu(a)

@@ -23,13 +23,20 @@ def _cases():
     return m.CASES
 
 
+def _fast(case):
+    spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.FAST_SEARCH.get(case, 0)
+
+
 def dbk_emu(out_arr, rec, w, h, beta=0, tc=0):
     lib = C.CDLL(os.path.join(ROOT, "tests", "emu", "libdbk_emu.so"))
     lib.dbk_emu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
     lib.dbk_emu(C.addressof(out_arr), rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, w, h, beta, tc)
 
 
-@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37"])
+@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32"])
 def test_emulated_engine_p_pictures(case, built, pkg):
     gen, w, h, base_qp, seed, n_pic, sr = _cases()[case]
     g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
@@ -41,8 +48,8 @@ def test_emulated_engine_p_pictures(case, built, pkg):
         if poc == 0:
             o, e = hmo_py.Encoder(*f, qp, lambda_override=lam), emu_py.EmuEncoder(*f, qp, lam=lam)
         else:
-            o = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
-            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr)
+            o = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=_fast(case))
+            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case))
         for a in range(o.n_ctu):
             o.compress_ctu(a)
             e.compress_ctu(a)
