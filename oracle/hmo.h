@@ -112,6 +112,7 @@ typedef struct {
   int had_me;                   /* HadamardME: SATD in the fractional search / merge estimation */
   int fdm;                      /* FDM (getUseFastDecisionForMerge) */
   int max_merge_cand;           /* MaxNumMergeCand (5) */
+  int rdoq, rdoq_ts;            /* RDOQ / RDOQTS (1, 1): 0 = the plain quantiser of xQuant with signBitHidingHDQ */
   double lambda_override;       /* > 0: slice lambda given by the caller (P-slice QP factor, TEncSlice.cpp:686-706) */
   unsigned lambda_motion_sad, lambda_motion_sse;   /* m_uiLambdaMotionSAD / SSE, TComRdCost.cpp:194-219 */
 } HmoParams;

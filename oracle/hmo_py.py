@@ -15,7 +15,7 @@ class Params(C.Structure):
                 ("strong_smoothing", C.c_int), ("lambda_", C.c_double), ("sqrt_lambda", C.c_double),
                 ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
-                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("lambda_override", C.c_double),
+                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
                 ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint)]
 
 

@@ -960,7 +960,7 @@ void hmo_params_default(HmoParams *p, int width, int height, int qp)
   memset(p, 0, sizeof(*p));
   p->width = width; p->height = height; p->qp = qp; p->slice_ctus = 0;
   p->transform_skip = 1; p->transform_skip_fast = 1; p->sign_hiding = 1; p->strong_smoothing = 1;
-  p->slice_type = HMO_SLICE_I; p->search_range = 64; p->fast_search = 0; p->fast_enc = 1; p->had_me = 1; p->fdm = 1; p->max_merge_cand = 5;
+  p->slice_type = HMO_SLICE_I; p->search_range = 64; p->fast_search = 0; p->rdoq = 1; p->rdoq_ts = 1; p->fast_enc = 1; p->had_me = 1; p->fdm = 1; p->max_merge_cand = 5;
   hmo_params_finish(p);
 }
 /* TEncSlice::initEncSlice lambda (TEncSlice.cpp:686-706) + setUpLambda (:496-524) + TComRdCost::setLambda */

@@ -128,9 +128,64 @@ static uint32_t coded_level(const HmoCabac *c, double lambda, double *codedCost,
 /* xRateDistOptQuant, TComTrQuant.cpp:2033-2573.  Rate tables (estBit, TEncSbac.cpp:1722-1956)
  * are read straight from the go-on coder's contexts, which estBit snapshots right before.
  * Returns uiAbsSum.  `part` = GetAbsPartIdxTU(compID), `trDepthRel` = GetTransformDepthRel(). */
+/* The quantiser without RDOQ: xQuant's else branch (TComTrQuant.cpp:1160-1240) + signBitHidingHDQ (:991-1124).  Levels are
+ * (|c| * scale + add) >> qbits with add = 171 (I slice) / 85 (else) << (qbits - 9); uiAbsSum is the sum before sign hiding. */
+static int quant_plain(HmoEnc *e, const HmoCU *cu, int comp, const int32_t *src, int32_t *dst, int log2, int part)
+{
+  const int N = 1 << log2, n2 = N * N;
+  const int qp = comp ? e->p.qp_c : e->p.qp, per = qp / 6, rem = qp % 6;
+  const int qbits = 14 + per + (15 - 8 - log2), qbits8 = qbits - 8;
+  const int64_t add = (int64_t)(e->p.slice_type == HMO_SLICE_I ? 171 : 85) << (qbits - 9);
+  const int qcoef = hmo_quant_scales[rem];
+  int32_t *deltaU = e->rq_delta_u;
+  int absSum = 0;
+  for (int i = 0; i < n2; i++) {
+    const int32_t c = src[i];
+    const int64_t t = (int64_t)(c < 0 ? -c : c) * qcoef;
+    const int32_t q = (int32_t)((t + add) >> qbits);
+    deltaU[i] = (int32_t)((t - ((int64_t)q << qbits)) >> qbits8);
+    absSum += q;
+    dst[i] = clip3(-32768, 32767, c < 0 ? -q : q);
+  }
+  if (e->p.sign_hiding && absSum >= 2) {
+    const uint16_t *scan = hmo_scan_tab[hmo_coef_scan_idx(cu, part, log2, comp)][log2 - 2];
+    int lastCG = -1;
+    for (int subSet = (n2 - 1) >> 4; subSet >= 0; subSet--) {
+      const int subPos = subSet << 4;
+      int first = 16, last = -1, sum = 0, n;
+      for (n = 15; n >= 0; --n) if (dst[scan[n + subPos]]) { last = n; break; }
+      for (n = 0; n < 16; n++) if (dst[scan[n + subPos]]) { first = n; break; }
+      for (n = first; n <= last; n++) sum += dst[scan[n + subPos]];
+      if (last >= 0 && lastCG == -1) lastCG = 1;
+      if (last - first >= 4) {                               /* SBH_THRESHOLD */
+        const uint32_t signbit = dst[scan[subPos + first]] > 0 ? 0 : 1;
+        if (signbit != (uint32_t)(sum & 1)) {
+          int32_t curCost = 0x7fffffff, minCostInc = 0x7fffffff; int minPos = -1, finalChange = 0, curChange = 0;
+          for (n = (lastCG == 1 ? last : 15); n >= 0; --n) {
+            const int blk = scan[n + subPos];
+            if (dst[blk] != 0) {
+              if (deltaU[blk] > 0) { curCost = -deltaU[blk]; curChange = 1; }
+              else if (n == first && (dst[blk] == 1 || dst[blk] == -1)) curCost = 0x7fffffff;
+              else { curCost = deltaU[blk]; curChange = -1; }
+            } else if (n < first) {
+              const uint32_t thisSign = src[blk] >= 0 ? 0 : 1;
+              if (thisSign != signbit) curCost = 0x7fffffff; else { curCost = -deltaU[blk]; curChange = 1; }
+            } else { curCost = -deltaU[blk]; curChange = 1; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = blk; }
+          }
+          if (dst[minPos] == 32767 || dst[minPos] == -32768) finalChange = -1;
+          if (src[minPos] >= 0) dst[minPos] += finalChange; else dst[minPos] -= finalChange;
+        }
+      }
+      if (lastCG == 1) lastCG = 0;
+    }
+  }
+  return absSum;
+}
+
 int hmo_rdoq(HmoEnc *e, const HmoCU *cu, const HmoTU *tu, int comp, const int32_t *src, int32_t *dst, int log2, int part, int tskip)
 {
-  (void)tskip;
+  if (!(tskip ? e->p.rdoq_ts : e->p.rdoq)) return quant_plain(e, cu, comp, src, dst, log2, part);     /* xQuant: useRDOQ = useTransformSkip ? m_useRDOQTS : m_useRDOQ */
   const HmoCabac *c = &e->goon;
   const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
   const int qp = comp ? e->p.qp_c : e->p.qp;
