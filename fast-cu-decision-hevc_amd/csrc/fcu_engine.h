@@ -190,6 +190,7 @@ struct Params {
   long long rd_factor[2];     /* sign-hiding rdFactor,   TComTrQuant.cpp:2444-2447 */
   /* P slices (BASELINE configs[4]) */
   int search_range, fast_enc, had_me, fdm, max_merge_cand, fast_search;
+  int rdoq, rdoq_ts;           /* RDOQ / RDOQTS: 0 = the plain quantiser of xQuant (quant_plain) for blocks without / with transform skip */
   uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
 };
 
@@ -713,6 +714,66 @@ FCU_DEV uint32_t coded_level(CB cb, double lambda, double *codedCost, double *co
  * non-zero level (-1: none). */
 struct RdoqOut { int abs_sum, last; };
 /* EST = 1: the caller has built g_S.est for coder `c` (est_build); EST = 0: costs are looked up in the coder itself */
+/* The quantiser without RDOQ: xQuant's plain branch (TComTrQuant.cpp:1160-1240) + signBitHidingHDQ (:991-1124) in the
+ * engine's scan-order domain.  src = sign * |coefficient| * quantiser scale per scan position (stride st), dst = levels;
+ * positions above the coefficient group of topNZ can only quantise to 0 and are not touched (callers treat them as 0).
+ * abs_sum is the sum before sign hiding, as the reference returns it; last = highest non-zero scan position afterwards. */
+FCU_DEV FCU_NOINLINE RdoqOut quant_plain(const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, const Params &P)
+{
+  RdoqOut o = { 0, -1 };
+  if (topNZ < 0) return o;
+  const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
+  const int qp = comp ? P.qp_c : P.qp, qbits = rdoq_qbits(log2, qp), qbits8 = qbits - 8;
+  const long long add = (long long)(P.slice_type == SLICE_I ? 171 : 85) << (qbits - 9);
+  const int cgTop = topNZ >> 4;
+  int absSum = 0;
+  for (int sp = cgTop * 16 + 15; sp >= 0; sp--) {
+    const int32_t ld = srcg[sp * st];
+    const int q = (int)(((long long)iabs(ld) + add) >> qbits);
+    absSum += q;
+    dstg[sp * st] = (int16_t)clip3i(-32768, 32767, ld < 0 ? -q : q);
+  }
+  o.abs_sum = absSum;
+  if (P.sign_hiding && absSum >= 2) {
+    int lastCG = -1;
+    for (int cg = cgTop; cg >= 0; cg--) {
+      const int sub = cg << 4;
+      int lv[16], du[16];
+      int first = 16, last = -1, sum = 0;
+      for (int n = 0; n < 16; n++) {
+        const int32_t ld = srcg[(sub + n) * st]; lv[n] = dstg[(sub + n) * st];
+        du[n] = (int)(((long long)iabs(ld) - ((long long)iabs(lv[n]) << qbits)) >> qbits8);
+        if (lv[n]) { if (first == 16) first = n; last = n; }
+      }
+      for (int n = first; n <= last; n++) sum += lv[n];
+      if (last >= 0 && lastCG == -1) lastCG = 1;
+      if (last - first >= 4) {
+        const unsigned signbit = lv[first] > 0 ? 0 : 1;
+        if (signbit != (unsigned)(sum & 1)) {
+          int curCost = 0x7fffffff, minCostInc = 0x7fffffff, minPos = -1, finalChange = 0, curChange = 0;
+          for (int n = (lastCG == 1 ? last : 15); n >= 0; --n) {
+            if (lv[n] != 0) {
+              if (du[n] > 0) { curCost = -du[n]; curChange = 1; }
+              else if (n == first && iabs(lv[n]) == 1) curCost = 0x7fffffff;
+              else { curCost = du[n]; curChange = -1; }
+            } else if (n < first) {
+              const unsigned thisSign = srcg[(sub + n) * st] >= 0 ? 0 : 1;
+              if (thisSign != signbit) curCost = 0x7fffffff; else { curCost = -du[n]; curChange = 1; }
+            } else { curCost = -du[n]; curChange = 1; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = n; }
+          }
+          if (lv[minPos] == 32767 || lv[minPos] == -32768) finalChange = -1;
+          const int nv = srcg[(sub + minPos) * st] >= 0 ? lv[minPos] + finalChange : lv[minPos] - finalChange;
+          dstg[(sub + minPos) * st] = (int16_t)nv;
+        }
+      }
+      if (lastCG == 1) lastCG = 0;
+    }
+  }
+  for (int sp = cgTop * 16 + 15; sp >= 0; sp--) if (dstg[sp * st]) { o.last = sp; break; }
+  return o;
+}
+
 template <int SER, int EST>
 FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
 {
@@ -1572,7 +1633,8 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
       FCU_TIC(t8_);
       RdoqRec *rrec = G->r_rec; double *rcg = G->r_cg;
       const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      const RdoqOut o = rdoq<1, 1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg);
+      const RdoqOut o = (useTS ? P.rdoq_ts : P.rdoq) ? rdoq<1, 1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg)
+                                                     : quant_plain(G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, P);
       g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
       E.C->n_tu_trials++;
       FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */
@@ -1948,7 +2010,8 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
       const int mode = g_S.rd_mode[(lane >> tss)];
       RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
       const int cbfCtx = CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0);
-      const RdoqOut o = rdoq<0, 1>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg);
+      const RdoqOut o = ((lane & tss) ? P.rdoq_ts : P.rdoq) ? rdoq<0, 1>(CAB_CUR0 + d, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, coef_scan_idx(mode, log2, 0), cbfCtx, P, rrec, rcg)
+                                                            : quant_plain(G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 0, P);
       g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
       g_S.vc_dist[lane] = 0;
     }
@@ -2101,8 +2164,9 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
     FCU_FOR_LANES {                                          /* RDOQ: one candidate per lane, priced against its own coder */
       if (lane < nc) {
         RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
-        const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + lane, G->p_lscan + lane, G->p_qscan + lane, nc, g_S.vc_last[lane], log2, 0,
-                                     coef_scan_idx(g_S.rd_mode[lane], log2, 0), CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0), P, rrec, rcg);
+        const RdoqOut o = P.rdoq ? rdoq<0, 0>(CAB_LANE0 + lane, G->p_lscan + lane, G->p_qscan + lane, nc, g_S.vc_last[lane], log2, 0,
+                                              coef_scan_idx(g_S.rd_mode[lane], log2, 0), CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0), P, rrec, rcg)
+                                 : quant_plain(G->p_lscan + lane, G->p_qscan + lane, nc, g_S.vc_last[lane], log2, 0, P);
         g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last; g_S.vc_dist[lane] = 0;
       }
       if (lane == 0) E.C->n_tu_trials += (unsigned long long)nc;
@@ -2392,7 +2456,9 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
         const int b = (lane >> tss), m = b % 5, comp = comp0 + b / 5;
         const int mode = g_S.c_modes[m] == DM_CHROMA ? lumaDir : g_S.c_modes[m];
         RdoqRec *rrec = G->r_rec + lane; double *rcg = G->r_cg + lane;
-        const RdoqOut o = rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 1 /* Cb and Cr share every parameter the call reads; the argument is wave-uniform */, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg);
+        const RdoqOut o = ((lane & tss) ? P.rdoq_ts : P.rdoq)
+          ? rdoq<0, 0>(CAB_LANE0 + m, G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 1 /* Cb and Cr share every parameter the call reads; the argument is wave-uniform */, coef_scan_idx(mode, log2, comp), CTX_CBF_CHROMA + trDepth, P, rrec, rcg)
+          : quant_plain(G->p_lscan + lane, G->p_qscan + lane, nvc, g_S.vc_last[lane], log2, 1, P);
         g_S.vc_abs[lane] = o.abs_sum; g_S.vc_lsp[lane] = o.last;
         g_S.vc_dist[lane] = 0;
       }

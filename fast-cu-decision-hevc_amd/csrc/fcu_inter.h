@@ -741,7 +741,9 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       if (lane < 6 && vok(lane) && ((lane >> 1) != 0) == (ch != 0)) {
         const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane);
         const int cbfCtx = (comp == 0 && trMode == 0) ? EST_ROOT_CBF : qt_cbf_ctx(tu, comp);      /* blockRootCbpBits, TComTrQuant.cpp:2358 */
-        const RdoqOut r = rdoq<0, 1>(CAB_GOON, G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp ? 1 : 0, 0, cbfCtx, P, G->r_rec + o, G->r_cg + lane * 64);   /* Cb and Cr share every parameter the call reads */
+        const RdoqOut r = ((lane & 1) ? P.rdoq_ts : P.rdoq)
+          ? rdoq<0, 1>(CAB_GOON, G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp ? 1 : 0, 0, cbfCtx, P, G->r_rec + o, G->r_cg + lane * 64)   /* Cb and Cr share every parameter the call reads */
+          : quant_plain(G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp ? 1 : 0, P);
         g_S.iv_abs[lane] = r.abs_sum; g_S.iv_lsp[lane] = r.last;
       }
       if (lane == 0 && ch == 0) E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0));

@@ -92,6 +92,8 @@ typedef struct fcu_frame_params {
   int fast_merge_decision;       /* FDM                                                                                  */
   int max_merge_cand;            /* MaxNumMergeCand (5)                                                                  */
   int fast_search;               /* FastSearch: 0 = full search (xPatternSearch), 1 = TZ search (xTZSearch, HM's cfg default) */
+  int rdoq, rdoq_ts;             /* RDOQ / RDOQTS (fcu_default_frame_params: 1, 1): 0 = TComTrQuant::xQuant's plain quantiser with
+                                    signBitHidingHDQ for blocks without / with transform skip */
 } fcu_frame_params;
 enum { FCU_SLICE_I = 0, FCU_SLICE_P = 1 };
 #define FCU_REF_MARGIN_LUMA 80   /* border of a padded reference plane: g_uiMaxCUWidth + 16 (TComPic::create); chroma: 40 */

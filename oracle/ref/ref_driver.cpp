@@ -576,6 +576,11 @@ int ref_merge_cu(int ctu, int zidx, int depth, int cand, int noResidual, RefCuOu
   return numValid;
 }
 
+/* RDOQ / RDOQTS switches of the quantiser (TComTrQuant::init, TEncTop.cpp; xQuant reads them, TComTrQuant.cpp:1145-1147)
+ * and the slice type, which selects the rounding offset of the plain quantiser (:1199) */
+void ref_set_rdoq(int rdoq, int rdoqTS) { g_trq->m_useRDOQ = rdoq != 0; g_trq->m_useRDOQTS = rdoqTS != 0; }
+void ref_set_slice_type(int isP) { g_slice->setSliceType(isP ? P_SLICE : I_SLICE); }
+
 /* TZ search (FastSearch 1) starts non-2Nx2N / deeper searches from the integer vector of the last 2Nx2N search
  * (m_integerMv2Nx2N, TEncSearch.cpp:3822-3833): encoder state that the caller carries over from its own search */
 void ref_set_int_mv(int x, int y) { g_search->m_integerMv2Nx2N[0][0].set(x, y); }
