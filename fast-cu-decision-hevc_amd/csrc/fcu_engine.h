@@ -190,6 +190,7 @@ struct Params {
   long long rd_factor[2];     /* sign-hiding rdFactor,   TComTrQuant.cpp:2444-2447 */
   /* P slices (BASELINE configs[4]) */
   int search_range, fast_enc, had_me, fdm, max_merge_cand, fast_search;
+  int tmvp;                    /* TMVPMode: temporal merge / AMVP candidate from Chain::col */
   int rdoq, rdoq_ts;           /* RDOQ / RDOQTS: 0 = the plain quantiser of xQuant (quant_plain) for blocks without / with transform skip */
   uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
 };
@@ -215,6 +216,7 @@ struct Chain {
   uint8_t sw_skip[4], sw_term[4];
   const int16_t *obf;
   double ver[4][6];
+  const fcu_ctu_out *col;      /* TMVP: the reference picture's fcu_ctu_out array (its motion field), or null */
   int int_mv[2];               /* m_integerMv2Nx2N[list 0][ref 0]: integer vector of the chain's last 2Nx2N motion search (TZ search start point) */
   fcu_pu_trace *pu_trace;      /* optional [n_ctu][FCU_PUS_PER_CTU] record of the luma search (fcu_chain_set_pu_trace) */
 };

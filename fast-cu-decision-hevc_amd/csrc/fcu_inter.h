@@ -74,6 +74,30 @@ FCU_DEV Nb nb_motion(const Env E, const CuObj *cu, int nx, int ny, int cx, int c
 FCU_DEV int same_motion(const Nb &a, const Nb &b) { return a.mvx == b.mvx && a.mvy == b.mvy && a.ref == b.ref; }
 
 /* getInterMergeCandidates (P slice, no TMVP) -> g_S.mrg_mv / mrg_ref; one lane */
+/* ---- TMVP: the reference picture is the collocated picture (collocated_from_l0, collocated_ref_idx 0).  xGetColMVP
+ * (TComDataCU.cpp:3175-3242): the motion its fcu_ctu_out array holds at the top-left 4x4 partition of the 16x16 block that
+ * contains the position (what TComPic::compressMotion keeps); unavailable where that partition is intra.  One reference,
+ * consecutive pictures: both POC distances are 1, no scaling. */
+FCU_DEV int col_mvp(const Env E, int x, int y, int &mvx, int &mvy)
+{
+  const fcu_ctu_out *col = E.C->col;
+  if (!col) return 0;
+  const int xc = x & ~15, yc = y & ~15;
+  const fcu_ctu_out *c = &col[(yc >> 6) * E.C->w_ctu + (xc >> 6)];
+  const int z = zidx_of(xc & 63, yc & 63);
+  if (c->pred_mode[z] != MODE_INTER || c->ref_idx[z] < 0) return 0;
+  mvx = c->mv[z][0]; mvy = c->mv[z][1];
+  return 1;
+}
+/* bottom-right neighbour H when inside the picture and the CTU row (:2528-2563 / :2863-2900), else the PU centre */
+FCU_DEV int temporal_candidate(const Env E, int xP, int yP, int w, int h, int &mvx, int &mvy)
+{
+  if (!E.C->p.tmvp) return 0;
+  const int bx = xP + w, by = yP + h;
+  if (bx < E.C->p.width && by < E.C->p.height && (by & 63) != 0 && col_mvp(E, bx, by, mvx, mvy)) return 1;
+  return col_mvp(E, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), mvx, mvy);
+}
+
 FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
 {
   const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
@@ -98,10 +122,11 @@ FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
     const Nb b2 = nb_motion(E, cu, xP - 1, yP - 1, xP, yP);
     if (b2.avail && b2.inter && (!okA1 || !same_motion(a1, b2)) && (!okB1 || !same_motion(b1, b2))) FCU_ADD_MRG(b2);
   }
+  if (n < maxc) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, tx, ty)) { g_S.mrg_mv[n][0] = tx; g_S.mrg_mv[n][1] = ty; g_S.mrg_ref[n] = 0; n++; } }
   while (n < maxc) { g_S.mrg_mv[n][0] = g_S.mrg_mv[n][1] = 0; g_S.mrg_ref[n] = 0; n++; }
 #undef FCU_ADD_MRG
 }
-/* fillMvpCand (one reference picture, no TMVP) -> g_S.amvp; one lane */
+/* fillMvpCand (one reference picture) -> g_S.amvp; one lane */
 FCU_DEV FCU_NOINLINE void amvp_candidates(const CuObj *cu, int ps, int pu)
 {
   const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
@@ -122,6 +147,7 @@ FCU_DEV FCU_NOINLINE void amvp_candidates(const CuObj *cu, int ps, int pu)
   if (haveAbove) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }
   if (!addedSmvp && haveAbove && n < 2) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }        /* xAddMVPCandOrder repeats it */
   if (n == 2 && g_S.amvp[0][0] == g_S.amvp[1][0] && g_S.amvp[0][1] == g_S.amvp[1][1]) n = 1;
+  if (n < 2) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, tx, ty)) { g_S.amvp[n][0] = tx; g_S.amvp[n][1] = ty; n++; } }   /* appended, then the list is cut to two */
   while (n < 2) { g_S.amvp[n][0] = g_S.amvp[n][1] = 0; n++; }
 }
 FCU_DEV void clip_mv(const Params &P, const CuObj *cu, int &x, int &y)            /* clipMv, TComDataCU.cpp:2930-2942 */

@@ -340,6 +340,18 @@ int fcu_chain_set_decision(fcu_ctx *c, int chain, const fcu_decision_params *dp)
   return FCU_OK;
 }
 
+int fcu_chain_set_collocated(fcu_ctx *c, int chain, const fcu_ctu_out *dev_col_out)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains) return fail(FCU_ERR_ARG, "fcu_chain_set_collocated: bad argument");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_collocated: chain not bound (fcu_chain_begin)");
+  if (dev_col_out == h.out) return fail(FCU_ERR_ARG, "fcu_chain_set_collocated: the collocated picture's array is the chain's own output array");
+  HIPCHK(hipSetDevice(c->sp.device));
+  h.col = dev_col_out;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, col), &h.col, sizeof(h.col), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
 int fcu_pu_index(int depth, int nxn, int zidx) { return nxn ? 85 + zidx : (depth <= 0 ? 0 : depth == 1 ? 1 + (zidx >> 6) : depth == 2 ? 5 + (zidx >> 4) : 21 + (zidx >> 2)); }
 int fcu_chain_set_pu_trace(fcu_ctx *c, int chain, fcu_pu_trace *dev_trace)
 {

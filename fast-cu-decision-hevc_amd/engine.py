@@ -28,7 +28,7 @@ class FrameParams(C.Structure):
                 ("lambda_", C.c_double), ("sqrt_lambda", C.c_double), ("chroma_weight", C.c_double),
                 ("rdoq_lambda", C.c_double * 3),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_enc", C.c_int), ("hadamard_me", C.c_int),
-                ("fast_merge_decision", C.c_int), ("max_merge_cand", C.c_int), ("fast_search", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int)]
+                ("fast_merge_decision", C.c_int), ("max_merge_cand", C.c_int), ("fast_search", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int)]
 
 
 class SeqParams(C.Structure):
@@ -85,7 +85,7 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
            "fcu_build_info", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full",
-           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index"]
+           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index", "fcu_chain_set_collocated"]
 
 SLICE_I, SLICE_P = 0, 1
 PUS_PER_CTU = 341
@@ -157,6 +157,7 @@ def load_lib():
     lib.fcu_sao_update_rate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.fcu_ldp_layer.argtypes = [C.c_int]
     lib.fcu_chain_set_pu_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.fcu_chain_set_collocated.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 
@@ -259,10 +260,11 @@ class CuEngine:
             raise FcuError(f"{what} failed ({r}): {self.lib.fcu_last_error().decode()}")
 
     # -- TEncCu::init + slice parameters
-    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, ref=None, params=None, **flags):
+    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, ref=None, params=None, col=None, **flags):
         """org: (Y,U,V) uint8 torch tensors on this device (or numpy arrays, uploaded once).
         params: a FrameParams to start from (e.g. ldp_slice(base_qp, poc)) instead of the I-slice defaults for `qp`;
-        ref: padded reference planes from pad_reference() -- required for a P slice."""
+        ref: padded reference planes from pad_reference() -- required for a P slice;
+        col: the reference picture's fcu_ctu_out array (TMVP, with params.tmvp = 1)."""
         torch = self.torch
         dev = torch.device("cuda", self.device)
         planes = []
@@ -290,6 +292,10 @@ class CuEngine:
         if ref is not None:
             self._chk(self.lib.fcu_chain_set_reference(self.h, chain, *[p.data_ptr() for p in ref]), "fcu_chain_set_reference")
             self._keep_ref[chain] = ref
+        if col is not None:                                   # TMVP: the reference picture's fcu_ctu_out array (uint8 device tensor)
+            assert col.is_cuda and col.numel() >= self.n_ctu * CTU_OUT_BYTES
+            self._chk(self.lib.fcu_chain_set_collocated(self.h, chain, col.data_ptr()), "fcu_chain_set_collocated")
+            self._keep_ref[("col", chain)] = col
         return rec, out
 
     def pad_reference(self, planes, stream=None):

@@ -19,13 +19,15 @@ class LowDelayPDecider:
     """`n_clips` clips of width x height decided picture by picture on one GPU.
     slice_ctus: CTUs per slice (HM SliceMode 1); None = one slice per picture (the reference configuration)."""
 
-    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, device=0):
+    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, tmvp=False, fast_search=1, device=0):
         self.width, self.height, self.base_qp, self.n_clips, self.search_range = width, height, base_qp, n_clips, search_range
         n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
         self.slice_ctus = slice_ctus if slice_ctus else n_ctu
         self.n_slices = (n_ctu + self.slice_ctus - 1) // self.slice_ctus
         self.eng = _engine.CuEngine(width, height, max_chains=n_clips * self.n_slices, device=device)
         self.do_deblock = deblock
+        self.tmvp, self.fast_search = tmvp, fast_search    # TMVPMode / FastSearch of the reference cfg (TZ search by default)
+        self.col = [None] * n_clips                      # fcu_ctu_out array of each clip's previous picture (TMVP motion field)
         self.do_sao = sao                                # SAO 1 of the reference's cfg; off by default: the loop-filter goldens stop at deblocking
         self.sao_rate = [_engine.SaoRate() for _ in range(n_clips)]      # m_saoDisabledRate per clip
         self.poc = 0
@@ -34,6 +36,8 @@ class LowDelayPDecider:
     def frame_params(self, poc):
         fp = _engine.ldp_slice(self.base_qp, poc)
         fp.search_range = self.search_range
+        fp.fast_search = self.fast_search
+        fp.tmvp = 1 if (self.tmvp and poc > 0) else 0
         return fp
 
     def decide_picture(self, frames):
@@ -47,11 +51,12 @@ class LowDelayPDecider:
         for s, f in enumerate(frames):
             first = s * self.n_slices
             ref = self.ref[s] if fp.slice_type == _engine.SLICE_P else None
-            rec, out = eng.init_chain(first, f, fp.qp, slice_ctus=self.slice_ctus if self.n_slices > 1 else 0, params=fp, ref=ref)
+            col = self.col[s] if fp.tmvp else None
+            rec, out = eng.init_chain(first, f, fp.qp, slice_ctus=self.slice_ctus if self.n_slices > 1 else 0, params=fp, ref=ref, col=col)
             planes = eng._keep[first][0]
             for k in range(self.n_slices):
                 if k:
-                    eng.init_chain(first + k, planes, fp.qp, slice_ctus=self.slice_ctus, rec=rec, out=out, params=fp, ref=ref)
+                    eng.init_chain(first + k, planes, fp.qp, slice_ctus=self.slice_ctus, rec=rec, out=out, params=fp, ref=ref, col=col)
                 if self.n_slices > 1:
                     a = k * self.slice_ctus
                     eng.set_range(first + k, a, min(self.slice_ctus, eng.n_ctu - a))
@@ -70,6 +75,7 @@ class LowDelayPDecider:
                 r["sao"], r["sao_enabled"] = coded[s], pics[s]["enabled"]
                 self.sao_rate[s].update(layer, off[s], eng.n_ctu)
         for s, r in enumerate(res):
+            self.col[s] = r["out"]                           # stays in HBM: the next picture's collocated motion field
             self.ref[s] = eng.pad_reference(r["rec"])          # reference of the next picture of this clip
         eng.sync()
         self.poc += 1

@@ -92,6 +92,8 @@ typedef struct fcu_frame_params {
   int fast_merge_decision;       /* FDM                                                                                  */
   int max_merge_cand;            /* MaxNumMergeCand (5)                                                                  */
   int fast_search;               /* FastSearch: 0 = full search (xPatternSearch), 1 = TZ search (xTZSearch, HM's cfg default) */
+  int tmvp;                      /* TMVPMode: temporal merge / AMVP candidate from the collocated picture = the reference picture
+                                    (collocated_from_l0, collocated_ref_idx 0); needs fcu_chain_set_collocated                */
   int rdoq, rdoq_ts;             /* RDOQ / RDOQTS (fcu_default_frame_params: 1, 1): 0 = TComTrQuant::xQuant's plain quantiser with
                                     signBitHidingHDQ for blocks without / with transform skip */
 } fcu_frame_params;
@@ -113,6 +115,11 @@ int  fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
  * planes made by fcu_pad_reference (pointers to the first byte of each padded plane; luma stride = width + 2 * 80).
  * Slice QP and lambda of picture `poc` under HM's lowdelay_P GOP table come from fcu_ldp_slice. */
 int  fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *dev_pad_y, const uint8_t *dev_pad_u, const uint8_t *dev_pad_v);
+/* TMVP: the motion field of the chain's reference picture = the fcu_ctu_out array that picture was decided into (device
+ * pointer, fcu_num_ctus() entries, kept alive by the caller).  What TComPic::compressMotion keeps (the top-left 4x4 partition
+ * of every 16x16 block) is read in place; frame_params.tmvp switches the temporal candidates on (TComDataCU.cpp:2528-2563,
+ * 2863-2900, xGetColMVP :3175-3242).  NULL: no collocated picture (every temporal candidate unavailable). */
+int  fcu_chain_set_collocated(fcu_ctx *c, int chain, const fcu_ctu_out *dev_col_out);
 /* Reference picture padding (TComPicYuv::extendPicBorder): copies the width x height planes into planes of
  * (width + 160) x (height + 160) luma / (width/2 + 80) x (height/2 + 80) chroma samples with the border replicated.
  * One kernel on `hip_stream`, asynchronous. */

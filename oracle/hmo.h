@@ -112,6 +112,7 @@ typedef struct {
   int had_me;                   /* HadamardME: SATD in the fractional search / merge estimation */
   int fdm;                      /* FDM (getUseFastDecisionForMerge) */
   int max_merge_cand;           /* MaxNumMergeCand (5) */
+  int tmvp;                     /* TMVPMode: temporal merge / AMVP candidate from the collocated (= reference) picture; needs hmo_set_col */
   int rdoq, rdoq_ts;            /* RDOQ / RDOQTS (1, 1): 0 = the plain quantiser of xQuant with signBitHidingHDQ */
   double lambda_override;       /* > 0: slice lambda given by the caller (P-slice QP factor, TEncSlice.cpp:686-706) */
   unsigned lambda_motion_sad, lambda_motion_sse;   /* m_uiLambdaMotionSAD / SSE, TComRdCost.cpp:194-219 */
@@ -179,6 +180,7 @@ typedef struct {
   double   best_cost;
   double   rmd_cost[8];
 } HmoPuTrace;
+void    hmo_set_col(HmoEnc *e, const HmoCtu *col);          /* decided CTUs of the reference picture (its motion field), kept alive by the caller */
 void    hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf);
 void    hmo_test_int_mv(const HmoEnc *e, int *xy);          /* m_integerMv2Nx2N as the search holds it now (TZ search state) */
 

@@ -109,6 +109,7 @@ struct HmoEnc {
   void (*trace)(void *user, int event, int depth, int arg);
   void *trace_user;
   struct { int x, y; } int_mv_2nx2n;           /* m_integerMv2Nx2N[list 0][ref 0]: integer vector of the last 2Nx2N motion search (TZ search start point) */
+  const HmoCtu *col;            /* motion field of the collocated picture (TMVP) */
   HmoPuTrace *pu_trace;         /* optional per-PU record of the luma search (hmo_set_pu_trace) */
 };
 /* trace events: candidate about to be searched / searched (its results sit in temp[depth], reco_temp[depth], slot[depth][CI_TEMP_BEST]) */

@@ -77,6 +77,30 @@ static HmoNb nb_motion(const HmoEnc *e, const HmoCU *cu, int nx, int ny, int cx,
 static int same_motion(const HmoNb *a, const HmoNb *b) { return a->mv.x == b->mv.x && a->mv.y == b->mv.y && a->ref == b->ref; }   /* hasEqualMotion, list 0 */
 
 /* getInterMergeCandidates for a P slice without TMVP: spatial A1, B1, B0, A0, B2, then zero candidates (refIdx 0) */
+/* ---- temporal motion vector prediction (TMVP), one reference picture = the collocated picture (collocated_from_l0,
+ * collocated_ref_idx 0).  xGetColMVP, TComDataCU.cpp:3175-3242: the motion the collocated picture holds at a position after
+ * TComPic::compressMotion (the top-left 4x4 partition of every 16x16 block stands for the block); not available where that
+ * partition is intra.  With consecutive pictures and one reference both POC distances are 1: no scaling (iScale == 4096). */
+static int col_mvp(const HmoEnc *e, int x, int y, HmoMv *mv)
+{
+  if (!e->col) return 0;
+  const int xc = x & ~15, yc = y & ~15;
+  const HmoCtu *c = &e->col[(yc >> 6) * e->w_ctu + (xc >> 6)];
+  const int z = zidx_of(xc & 63, yc & 63);
+  if (c->pred_mode[z] != HMO_MODE_INTER || c->ref_idx[z] < 0) return 0;
+  mv->x = c->mv[z][0]; mv->y = c->mv[z][1];
+  return 1;
+}
+/* the temporal candidate of a PU: bottom-right neighbour (H) when it lies inside the picture and in the same CTU row
+ * (TComDataCU.cpp:2528-2563 / :2863-2900), else the centre of the PU (xDeriveCenterIdx) */
+static int temporal_candidate(const HmoEnc *e, int xP, int yP, int w, int h, HmoMv *mv)
+{
+  if (!e->p.tmvp) return 0;
+  const int bx = xP + w, by = yP + h;
+  if (bx < e->p.width && by < e->p.height && (by & 63) != 0 && col_mvp(e, bx, by, mv)) return 1;
+  return col_mvp(e, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), mv);
+}
+
 static int merge_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int pu, HmoMv mv[5], int ref[5])
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
@@ -105,6 +129,8 @@ static int merge_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int 
     if (okB2 && (!okA1 || !same_motion(&a1, &b2)) && (!okB1 || !same_motion(&b1, &b2))) { mv[n] = b2.mv; ref[n] = b2.ref; n++; }
   }
   if (n == maxc) return n;
+  { HmoMv t; if (temporal_candidate(e, xP, yP, w, h, &t)) { mv[n] = t; ref[n] = 0; n++; } }
+  if (n == maxc) return n;
   while (n < maxc) { mv[n].x = mv[n].y = 0; ref[n] = 0; n++; }                /* zero candidates: one reference picture -> r stays 0 */
   return n;
 }
@@ -131,6 +157,7 @@ static void amvp_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int 
   if (haveAbove) cand[n++] = above;
   if (!addedSmvp && haveAbove && n < 2) cand[n++] = above;      /* xAddMVPCandOrder repeats the first inter above neighbour (:2852-2864) */
   if (n == 2 && cand[0].x == cand[1].x && cand[0].y == cand[1].y) n = 1;
+  { HmoMv t; if (n < 2 && temporal_candidate(e, xP, yP, w, h, &t)) cand[n++] = t; }    /* appended, then the list is cut to two (:2863-2925) */
   while (n < 2) { cand[n].x = cand[n].y = 0; n++; }
 }
 

@@ -15,7 +15,7 @@ class Params(C.Structure):
                 ("strong_smoothing", C.c_int), ("lambda_", C.c_double), ("sqrt_lambda", C.c_double),
                 ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
-                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
+                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
                 ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint)]
 
 
@@ -116,8 +116,9 @@ PUS_PER_CTU = 341
 class Encoder:
     """One chain: a frame (or its slices) decided CTU by CTU in raster order."""
 
-    def __init__(self, Y, U, V, qp, slice_ctus=0, ref=None, **flags):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, ref=None, col=None, **flags):
         """ref = (Y, U, V) planes of the reference picture makes this a P picture (slice_type P, list 0, index 0);
+        col = the reference picture's decided CTUs (bytes of its Ctu array: all_ctus_bytes()) switches TMVP on;
         flags: any Params field (search_range, fast_enc, lambda_override, ...)."""
         self.lib = load()
         h, w = Y.shape
@@ -126,6 +127,8 @@ class Encoder:
         self.p.slice_ctus = slice_ctus
         if ref is not None:
             self.p.slice_type = SLICE_P
+        if col is not None:
+            self.p.tmvp = 1
         known = {n for n, _ in Params._fields_}
         for k, v in flags.items():
             if k not in known:
@@ -141,6 +144,17 @@ class Encoder:
         if ref is not None:
             self.ref = [np.ascontiguousarray(a, dtype=np.uint8) for a in ref]
             self.lib.hmo_set_ref_planes(self.h, *[a.ctypes.data for a in self.ref])
+        self.col = None
+        if col is not None:
+            assert len(col) == C.sizeof(Ctu) * self.n_ctu
+            self.col = np.frombuffer(bytes(col), dtype=np.uint8).copy()
+            self.lib.hmo_set_col.argtypes = [C.c_void_p, C.c_void_p]
+            self.lib.hmo_set_col(self.h, self.col.ctypes.data)
+
+    def all_ctus_bytes(self):
+        """the decided picture's Ctu array as bytes (same layout as the engine's fcu_ctu_out array): the motion field a later
+        picture's TMVP reads"""
+        return b"".join(C.string_at(C.addressof(self.ctu(a)), C.sizeof(Ctu)) for a in range(self.n_ctu))
 
     def compress_ctu(self, a):
         self.lib.hmo_compress_ctu(self.h, a)

@@ -1037,6 +1037,7 @@ void hmo_decision_switch(const double *ver24, const double *th_skip, const doubl
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 /* test hooks (see hmo_int.h: trace) */
 void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
+void hmo_set_col(HmoEnc *e, const HmoCtu *col) { e->col = col; }
 void hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf) { e->pu_trace = buf; }
 void hmo_test_int_mv(const HmoEnc *e, int *xy) { xy[0] = e->int_mv_2nx2n.x; xy[1] = e->int_mv_2nx2n.y; }
 const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }

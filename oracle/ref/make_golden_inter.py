@@ -38,8 +38,11 @@ CASES = {      # name: (generator, width, height, base QP, seed, pictures, searc
     "textured_qp37": ("textured", 128, 64, 37, 9, 5, 32),        # all four GOP positions
     "tz_textured_qp32": ("textured", 192, 128, 32, 7, 3, 64),    # FastSearch 1 (TZ search), SearchRange 64: raster search, star refinement
     "tz_mixed_qp27": ("mixed", 136, 72, 27, 31, 3, 16),          # FastSearch 1, small window, partial CTUs
+    "tmvp_mixed_qp30": ("mixed", 192, 128, 30, 9, 4, 16),          # TMVPMode 1 (temporal merge / AMVP candidate) + TZ search
+    "tmvp_textured_qp35": ("textured", 136, 72, 35, 4, 4, 32),    # TMVP, partial CTUs (bottom-right candidates leaving the picture)
 }
-FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1}        # HM's FastSearch of a case (default 0 = full search)
+FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1, "tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1}        # HM's FastSearch of a case (default 0 = full search)
+TMVP = {"tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1}           # TMVP on: the collocated picture is the reference picture
 
 
 def run_case(case, ref_factory, on_picture):
@@ -52,6 +55,7 @@ def run_case(case, ref_factory, on_picture):
     spec.loader.exec_module(synth)
     gen, w, h, base_qp, seed, n_pic, sr = CASES[case]
     prev = None
+    prev_ctus = None
     out = []
     for poc in range(n_pic):
         f = st.moving_frame(synth, gen, w, h, seed, poc)
@@ -61,8 +65,11 @@ def run_case(case, ref_factory, on_picture):
             enc.compress_frame()
             out.append((None, None))
         else:
-            enc = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
+            col = prev_ctus if TMVP.get(case, 0) else None
+            enc = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
             ref = ref_factory(poc, f, qp, lam, prev, sr) if ref_factory else None
+            if ref and col is not None:
+                ref.setup_col(col, poc)
             irec, mrec, bad = [], [], [0]
 
             def on_event(ev, depth, arg, enc=enc, ref=ref, irec=irec, mrec=mrec, bad=bad):
@@ -95,6 +102,7 @@ def run_case(case, ref_factory, on_picture):
             enc.compress_frame()
             out.append((np.stack(mrec), np.stack(irec) if irec else np.zeros((0, len(st.FIELDS)), np.uint32)))
             on_picture(poc, enc, ref, bad[0])
+        prev_ctus = enc.all_ctus_bytes()
         enc.deblock()
         prev = [a.copy() for a in enc.rec]
         if poc == 0:

@@ -518,6 +518,30 @@ int ref_setup_p(const unsigned char *ry, const unsigned char *ru, const unsigned
   g_trq->setLambdas(lambdas);
   return 0;
 }
+/* TMVP: the reference picture as the collocated picture.  Its decided CTUs' prediction modes and list-0 motion are loaded,
+ * TComPic::compressMotion is run on it (as TEncGOP does after a picture is coded, TEncGOP.cpp:1497) and the current slice
+ * gets the collocated-picture syntax HM's lowdelay configuration produces (TMVP on, collocated_from_l0, collocated_ref_idx 0). */
+void ref_set_col_ctu(int ctu, const signed char *predMode, const short *mv, const signed char *refIdx)
+{
+  TComDataCU *c = g_refpic->getCtu(ctu);
+  if (c->getPic() == 0) c->initCtu(g_refpic, ctu);
+  TComCUMvField *f0 = c->getCUMvField(REF_PIC_LIST_0), *f1 = c->getCUMvField(REF_PIC_LIST_1);
+  for (int i = 0; i < 256; i++) {
+    const bool decided = predMode[i] == MODE_INTER || predMode[i] == MODE_INTRA;
+    c->getPredictionMode()[i] = decided ? predMode[i] : (signed char)NUMBER_OF_PREDICTION_MODES;
+    c->getPartitionSize()[i] = decided ? (signed char)SIZE_2Nx2N : (signed char)NUMBER_OF_PART_SIZES;
+    f0->m_pcMv[i].set(mv[2 * i], mv[2 * i + 1]); f0->m_piRefIdx[i] = predMode[i] == MODE_INTER ? refIdx[i] : -1;
+    f1->m_pcMv[i].set(0, 0); f1->m_piRefIdx[i] = -1;
+  }
+}
+void ref_col_finish(int poc)
+{
+  g_refpic->compressMotion();
+  TComSlice *cs = g_refpic->getSlice(0);
+  cs->setPOC(poc - 1); cs->setRefPOC(poc - 2, REF_PIC_LIST_0, 0); cs->setIsUsedAsLongTerm(REF_PIC_LIST_0, 0, false);
+  g_slice->setPOC(poc); g_slice->setRefPOCList();
+  g_slice->setEnableTMVPFlag(true); g_slice->setColFromL0Flag(1); g_slice->setColRefIdx(0); g_slice->setCheckLDC(true);
+}
 /* inter fields of a decided CTU: skip flags, inter direction, list-0 motion */
 void ref_set_ctu_inter(int ctu, const unsigned char *skip, const unsigned char *interDir, const unsigned char *mergeFlag, const short *mv, const signed char *refIdx)
 {

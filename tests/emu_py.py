@@ -24,6 +24,7 @@ def load():
     lib.fcu_emu_set_lambda.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.fcu_emu_get_state_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcu_emu_set_rdoq.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fcu_emu_set_col.argtypes = [C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -36,7 +37,7 @@ def pad_planes(planes):
 
 
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1, col=None):
         """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda)"""
         self.lib = load()
         h, w = Y.shape
@@ -47,6 +48,7 @@ class EmuEncoder:
         self.h = self.lib.fcu_emu_create(w, h, qp, slice_ctus, tools, *[a.ctypes.data for a in self.org],
                                          *[a.ctypes.data for a in self.rec], C.addressof(self.out))
         self._rdoq = (rdoq, rdoq_ts)
+        self._col = None if col is None else np.frombuffer(bytes(col), dtype=np.uint8).copy()      # TMVP: the reference picture's Ctu array
         if ref is not None:
             self.pad = pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in ref])
             self.lib.fcu_emu_set_p(self.h, qp, float(lam), search_range, fast_search, *[a.ctypes.data for a in self.pad])
@@ -62,6 +64,8 @@ class EmuEncoder:
 
     def compress_ctu(self, a):
         self.lib.fcu_emu_set_rdoq(self.h, *self._rdoq)           # (set_p / set_lambda rebuild the parameter block)
+        if self._col is not None:
+            self.lib.fcu_emu_set_col(self.h, self._col.ctypes.data)
         self.lib.fcu_emu_compress_ctu(self.h, a)
 
     def set_decision(self, state, obf=None, sw_skip=(0, 0, 0, 0), sw_term=(0, 0, 0, 0), depth_exception=0):

@@ -198,6 +198,15 @@ class RefSearch:
         self.base = st[:self.n_hm].copy()
         self.is_p = True
 
+    def setup_col(self, ctus_bytes, poc):
+        """TMVP: the reference picture's decided CTUs (Encoder.all_ctus_bytes()) become the collocated picture's motion field"""
+        L, vp = self.L, lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        n = C.sizeof(hmo_py.Ctu)
+        for a in range(self.n_ctu):
+            c = hmo_py.Ctu.from_buffer_copy(ctus_bytes[a * n:(a + 1) * n])
+            L.ref_set_col_ctu(a, vp(np.ctypeslib.as_array(c.pred_mode).copy()), vp(np.ctypeslib.as_array(c.mv).copy()), vp(np.ctypeslib.as_array(c.ref_idx).copy()))
+        L.ref_col_finish(poc)
+
     def load_inter_state(self, enc):
         """inter fields of the decided CTUs (current CTU and its left / above-row neighbours)"""
         L, vp = self.L, lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)

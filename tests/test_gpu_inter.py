@@ -22,21 +22,24 @@ def _same_ctu(got, want, tag):
             assert v == got[k], f"{tag}: {k}: engine {got[k]} oracle {v}"
 
 
-@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,fast", [("mixed", 136, 72, 27, 3, 8, 0), ("textured", 192, 128, 32, 3, 16, 0), ("smooth", 128, 64, 37, 5, 64, 0),
-                                                               ("mixed", 136, 72, 27, 3, 16, 1), ("textured", 192, 128, 32, 3, 64, 1)])     # fast = 1: TZ search (FastSearch 1)
-def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast):
+@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,fast,tmvp", [("mixed", 136, 72, 27, 3, 8, 0, 0), ("textured", 192, 128, 32, 3, 16, 0, 0), ("smooth", 128, 64, 37, 5, 64, 0, 0),
+                                                                    ("mixed", 136, 72, 27, 3, 16, 1, 0), ("textured", 192, 128, 32, 3, 64, 1, 0),      # fast = 1: TZ search (FastSearch 1)
+                                                                    ("mixed", 192, 128, 30, 4, 16, 1, 1), ("textured", 136, 72, 35, 4, 32, 0, 1)])     # tmvp = 1: temporal candidates
+def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast, tmvp):
     """compressCtu-shaped calls: every CTU of every picture of a short lowdelay_P clip, CABAC state after every CTU."""
     eng = pkg.CuEngine(w, h, max_chains=1)
-    prev, prev_pad = None, None
+    prev, prev_pad, prev_out, prev_ctus = None, None, None, None
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, 5, poc)
         fp = pkg.engine.ldp_slice(base_qp, poc)
         fp.search_range = sr
         fp.fast_search = fast
+        fp.tmvp = 1 if (tmvp and poc) else 0
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
         assert fp.qp == qp and fp.lambda_ == lam and fp.slice_type == (0 if poc == 0 else 1)
-        eng.init_chain(0, f, fp.qp, params=fp, ref=prev_pad)
-        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=fast)
+        eng.init_chain(0, f, fp.qp, params=fp, ref=prev_pad, col=prev_out if (tmvp and poc) else None)
+        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else \
+            hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, lambda_override=lam, search_range=sr, fast_search=fast)
         for a in range(eng.n_ctu):
             got = eng.compress_ctu(0, a)
             ref.compress_ctu(a)
@@ -45,6 +48,8 @@ def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast):
             assert fe == fo and np.array_equal(ce[st.O_SORTED], co[st.O_SORTED]), f"CABAC state poc{poc} ctu{a}"
         for p, q in zip(eng.rec_planes(0), ref.rec):
             assert np.array_equal(p, q), f"reconstruction poc{poc}"
+        prev_out, prev_ctus = eng._keep[0][2], ref.all_ctus_bytes()     # the picture's fcu_ctu_out array stays in HBM as the next picture's motion field
+        assert bytes(prev_out.cpu().numpy()) == prev_ctus
         eng.deblock(0)
         eng.sync()
         ref.deblock()
@@ -66,7 +71,7 @@ def test_ldp_416x240_clip_matches_oracle_and_reference_loop_filter(pkg):
     spec.loader.exec_module(m)
     gen, w, h, base_qp, seed, n_pic, sr = m.CASES["smooth416_qp32"]
     g = np.load(os.path.join(ROOT, "tests", "golden", "inter_smooth416_qp32.npz"))
-    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr)
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, fast_search=0)
     prev = None
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
@@ -93,7 +98,7 @@ def test_4k_pair_ctu_rows(pkg):
     the GPU (that path has its own 4K parity test); picture 1 (P, one CTU row per slice, SearchRange 16 to bound the
     oracle's CPU time) is compared with the oracle on the top row, an interior row and the partial bottom row."""
     w, h, base_qp, sr, sl = 3840, 2160, 32, 16, 60
-    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl)
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl, fast_search=0)
     f0 = st.moving_frame(pkg.synth, "textured", w, h, 7, 0)
     r0 = dec.decide_picture([f0])[0]
     prev = [p.cpu().numpy() for p in r0["rec"]]

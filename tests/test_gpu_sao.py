@@ -79,17 +79,20 @@ def test_device_pipeline_reproduces_the_reference_runs_psnr(pkg):
 
 
 def test_lowdelay_clip_with_sao_references(pkg):
-    """lowdelay_P with SAO 1 (the reference's configuration): every picture's reference is the deblocked AND SAO-filtered
-    predecessor; the slice switches follow m_saoDisabledRate of the lower temporal layer"""
+    """lowdelay_P as close to the reference's cfg as the path goes: SAO 1 (every picture's reference is the deblocked AND
+    SAO-filtered predecessor; the slice switches follow m_saoDisabledRate of the lower temporal layer), TZ search, TMVP (the
+    previous picture's fcu_ctu_out array is the collocated motion field)"""
     w, h, base_qp, sr, n_pic = 192, 128, 30, 16, 4
-    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, sao=True)
-    state, prev = hmo_py.SaoState(), None
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, sao=True, tmvp=True)
+    state, prev, prev_ctus = hmo_py.SaoState(), None, None
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, "mixed", w, h, 9, poc)
         stype, qp, lam = hmo_py.ldp_slice(poc, base_qp)
         r = dec.decide_picture([f])[0]
-        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+        ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus, lambda_override=lam, search_range=sr, fast_search=1)
         ref.compress_frame()
+        prev_ctus = ref.all_ctus_bytes()
+        assert bytes(r["out"].cpu().numpy()) == prev_ctus, poc
         ref.deblock()
         layer = hmo_py.ldp_layer(poc)
         assert layer == pkg.engine.ldp_layer(poc)

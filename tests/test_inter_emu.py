@@ -23,6 +23,13 @@ def _cases():
     return m.CASES
 
 
+def _tmvp(case):
+    spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.TMVP.get(case, 0)
+
+
 def _fast(case):
     spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
     m = importlib.util.module_from_spec(spec)
@@ -36,11 +43,12 @@ def dbk_emu(out_arr, rec, w, h, beta=0, tc=0):
     lib.dbk_emu(C.addressof(out_arr), rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, w, h, beta, tc)
 
 
-@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32"])
+@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32", "tmvp_mixed_qp30", "tmvp_textured_qp35"])
 def test_emulated_engine_p_pictures(case, built, pkg):
     gen, w, h, base_qp, seed, n_pic, sr = _cases()[case]
     g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
     prev = None
+    prev_ctus = None
     n_inter = n_skip = 0
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
@@ -48,8 +56,9 @@ def test_emulated_engine_p_pictures(case, built, pkg):
         if poc == 0:
             o, e = hmo_py.Encoder(*f, qp, lambda_override=lam), emu_py.EmuEncoder(*f, qp, lam=lam)
         else:
-            o = hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=_fast(case))
-            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case))
+            col = prev_ctus if _tmvp(case) else None
+            o = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=_fast(case))
+            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case), col=col)
         for a in range(o.n_ctu):
             o.compress_ctu(a)
             e.compress_ctu(a)
@@ -62,6 +71,8 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             n_skip += int(A["skip"].sum())
         for p, q in zip(o.rec, e.rec):
             assert np.array_equal(p, q), (poc, "reconstruction")
+        prev_ctus = bytes(e.out)                                 # the engine's own array is the next picture's motion field (TMVP)
+        assert prev_ctus == o.all_ctus_bytes()
         dbk_emu(e.out, e.rec, w, h)                              # kernel source on the CPU, in place
         if poc:
             assert [st.crc(p) for p in e.rec] == [int(v) for v in g[f"deblock_{poc}"][:3]], (poc, "deblocked picture vs the reference's loop filter")
