@@ -95,6 +95,7 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
   const TComPPS *pps = slice->getPPS();
   fp.transform_skip = pps->getUseTransformSkip(); fp.transform_skip_fast = cfg->getUseTransformSkipFast();
   fp.sign_hiding = pps->getSignHideFlag(); fp.strong_intra_smoothing = slice->getSPS()->getUseStrongIntraSmoothing();
+  fp.rdoq = cfg->getUseRDOQ(); fp.rdoq_ts = cfg->getUseRDOQTS();
   const int first = (int)pic->getPicSym()->getCtuTsToRsAddrMap(slice->getSliceCurStartCtuTsAddr());
   const int count = (int)(slice->getSliceCurEndCtuTsAddr() - slice->getSliceCurStartCtuTsAddr());
   fp.slice_ctus = cfg->getSliceMode() == FIXED_NUMBER_OF_CTU ? cfg->getSliceArgument() : 0;
@@ -103,6 +104,9 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     fp.slice_type = FCU_SLICE_P;
     fp.search_range = cfg->getSearchRange(); fp.fast_enc = cfg->getUseFastEnc(); fp.hadamard_me = cfg->getUseHADME();
     fp.fast_merge_decision = cfg->getUseFastDecisionForMerge(); fp.max_merge_cand = slice->getMaxNumMergeCand();
+    fp.fast_search = cfg->getFastSearch() ? 1 : 0;
+    if (slice->getEnableTMVPFlag()) { fprintf(stderr, "TEncCuFcu: run HM with TMVPMode 0 (the collocated motion field is not uploaded by this adapter yet)\n"); exit(1); }
+    if (slice->getSPS()->getUseAMP()) { fprintf(stderr, "TEncCuFcu: run HM with AMP 0 (asymmetric partitions are not behind the ABI)\n"); exit(1); }
   }
   int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
   if (rc != FCU_OK) die("fcu_chain_begin", rc);

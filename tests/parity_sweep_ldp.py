@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle sweep of the lowdelay_P pipeline (a measurement script, not part of the test suite): short clips
 of random size (off the CTU grid), base QP, content and motion; per picture random slices, search range, TZ / full search,
-RDOQ / RDOQTS, tool flags; decide -> deblock (random offsets) -> optional SAO -> padded reference of the next picture.
+RDOQ / RDOQTS, TMVP, tool flags; decide -> deblock (random offsets) -> optional SAO -> padded reference of the next picture.
 Every fcu_ctu_out field, the reconstruction, the coder state, the deblocked and SAO-filtered planes and the signalled SAO
 parameters must be identical to the oracle's.  One line per clip and a summary; exit code 1 on any mismatch."""
 import argparse
@@ -55,11 +55,12 @@ def main():
         tools = dict(transform_skip=int(rng.random() < 0.8), transform_skip_fast=int(rng.integers(0, 2)), sign_hiding=int(rng.random() < 0.8),
                      strong_intra_smoothing=int(rng.integers(0, 2)))
         sao = int(rng.random() < 0.6)
+        tmvp = int(rng.random() < 0.5)
         boff, toff = int(rng.integers(-2, 3)), int(rng.integers(-2, 3))
         big = getattr(pkg.synth, gen)(w + 64, h + 64, seed=seed)
         eng = pkg.CuEngine(w, h, max_chains=1)
         rate_e, rate_o = pkg.engine.SaoRate(), hmo_py.SaoState()
-        prev = pad = None
+        prev = pad = prev_out = prev_ctus = None
         diffs = []
         for poc in range(n_pic):
             ox, oy = 32 + dxy[0] * poc, 32 + dxy[1] * poc
@@ -73,15 +74,16 @@ def main():
             if not (0 <= qp <= 51):
                 break
             fp.search_range, fp.fast_search, fp.rdoq, fp.rdoq_ts = sr, fast, rdoq, rdoq_ts
+            fp.tmvp = 1 if (tmvp and poc) else 0
             for k, v in tools.items():
                 setattr(fp, k, v)
-            eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, ref=pad)
+            eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, ref=pad, col=prev_out if fp.tmvp else None)
             eng.compress_chains(0, 1, n_ctu)
             eng.sync()
             ot = dict(tools)
             ot["strong_smoothing"] = ot.pop("strong_intra_smoothing")
             kw = dict(slice_ctus=sl, lambda_override=lam, rdoq=rdoq, rdoq_ts=rdoq_ts, **ot)
-            o = hmo_py.Encoder(*f, qp, **kw) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, search_range=sr, fast_search=fast, **kw)
+            o = hmo_py.Encoder(*f, qp, **kw) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, search_range=sr, fast_search=fast, **kw)
             o.compress_frame()
             for a in range(n_ctu):
                 got, want = eng.ctu_out(0, a), o.ctu_arrays(a)
@@ -93,6 +95,7 @@ def main():
             (ce, fe), (co, fo) = eng.ctx_state(0, full=True), o.cabac(full=True)
             if fe != fo or not np.array_equal(ce[:175], co[:175]):
                 diffs.append(f"poc{poc}.cabac")
+            prev_out, prev_ctus = eng._keep[0][2], o.all_ctus_bytes()
             eng.deblock(0, boff, toff)
             eng.sync()
             o.deblock(boff, toff)
@@ -118,7 +121,7 @@ def main():
         eng.destroy()
         bad += bool(diffs)
         print(f"clip {clip:3d} {gen:8s} {w}x{h} qp{base_qp:2d} pics {n_pic} motion {dxy} slice_ctus {sl} sr {sr} fast {fast} rdoq {rdoq}/{rdoq_ts} "
-              f"tools {list(tools.values())} sao {sao} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
+              f"tools {list(tools.values())} sao {sao} tmvp {tmvp} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
     print(f"{args.clips - bad} of {args.clips} clips identical")
     sys.exit(1 if bad else 0)
 
