@@ -37,6 +37,10 @@ extern "C" {
 #define HMO_SIZE_2NxN    1
 #define HMO_SIZE_Nx2N    2
 #define HMO_SIZE_NxN     3
+#define HMO_SIZE_2NxnU   4      /* asymmetric motion partitions (AMP): 1/4 + 3/4 */
+#define HMO_SIZE_2NxnD   5
+#define HMO_SIZE_nLx2N   6
+#define HMO_SIZE_nRx2N   7
 #define HMO_SIZE_NONE    8      /* NUMBER_OF_PART_SIZES */
 #define HMO_MODE_INTER   0
 #define HMO_MODE_INTRA   1
@@ -112,6 +116,7 @@ typedef struct {
   int had_me;                   /* HadamardME: SATD in the fractional search / merge estimation */
   int fdm;                      /* FDM (getUseFastDecisionForMerge) */
   int max_merge_cand;           /* MaxNumMergeCand (5) */
+  int amp;                      /* AMP: asymmetric inter partitions at depths 0..2 with HM's AMP_ENC_SPEEDUP / AMP_MRG test selection */
   int tmvp;                     /* TMVPMode: temporal merge / AMVP candidate from the collocated (= reference) picture; needs hmo_set_col */
   int rdoq, rdoq_ts;            /* RDOQ / RDOQTS (1, 1): 0 = the plain quantiser of xQuant with signBitHidingHDQ */
   double lambda_override;       /* > 0: slice lambda given by the caller (P-slice QP factor, TEncSlice.cpp:686-706) */

@@ -53,6 +53,11 @@ static int edge_flag(const Dbk *d, int dir, int x4, int y4)
   if (c->part_size[z] == HMO_SIZE_2NxN && dir == 1 && (pos % cu) == cu / 2) return 2;
   if (c->part_size[z] == HMO_SIZE_Nx2N && dir == 0 && (pos % cu) == cu / 2) return 2;
   if (c->part_size[z] == HMO_SIZE_NxN && (pos % cu) == cu / 2) return 2;
+  /* asymmetric partitions: the edge at a quarter of the CU (:331-350); only 32x32 and 64x64 CUs put it on the 8-sample grid */
+  if (c->part_size[z] == HMO_SIZE_2NxnU && dir == 1 && (pos % cu) == cu / 4) return 2;
+  if (c->part_size[z] == HMO_SIZE_2NxnD && dir == 1 && (pos % cu) == cu - cu / 4) return 2;
+  if (c->part_size[z] == HMO_SIZE_nLx2N && dir == 0 && (pos % cu) == cu / 4) return 2;
+  if (c->part_size[z] == HMO_SIZE_nRx2N && dir == 0 && (pos % cu) == cu - cu / 4) return 2;
   return 0;
 }
 /* xGetBoundaryStrengthSingle, :405-553 (P slices with one reference picture list): P = left / above partition */

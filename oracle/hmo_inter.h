@@ -29,21 +29,24 @@ typedef struct { int x, y; } HmoMv;
 static int pu_count(int partSize) { return partSize == HMO_SIZE_2Nx2N ? 1 : (partSize == HMO_SIZE_NxN ? 4 : 2); }
 static void pu_geom(const HmoCU *cu, int partSize, int pu, int *addr, int *ox, int *oy, int *w, int *h)
 {
-  const int s = cu_size(cu), n = cu->nparts;
+  const int s = cu_size(cu), n = cu->nparts, q = s >> 2;
   *addr = 0; *ox = 0; *oy = 0; *w = s; *h = s;
-  if (partSize == HMO_SIZE_2NxN) { *h = s >> 1; if (pu) { *addr = n >> 1; *oy = s >> 1; } }
-  else if (partSize == HMO_SIZE_Nx2N) { *w = s >> 1; if (pu) { *addr = n >> 2; *ox = s >> 1; } }
-  else if (partSize == HMO_SIZE_NxN) { *w = *h = s >> 1; *addr = pu * (n >> 2); *ox = (pu & 1) * (s >> 1); *oy = (pu >> 1) * (s >> 1); }
+  switch (partSize) {
+  case HMO_SIZE_2NxN: *h = s >> 1; if (pu) { *addr = n >> 1; *oy = s >> 1; } break;
+  case HMO_SIZE_Nx2N: *w = s >> 1; if (pu) { *addr = n >> 2; *ox = s >> 1; } break;
+  case HMO_SIZE_NxN: *w = *h = s >> 1; *addr = pu * (n >> 2); *ox = (pu & 1) * (s >> 1); *oy = (pu >> 1) * (s >> 1); break;
+  case HMO_SIZE_2NxnU: if (!pu) *h = q; else { *h = s - q; *oy = q; *addr = n >> 3; } break;                 /* getPartIndexAndSize, TComDataCU.cpp:2165-2240 */
+  case HMO_SIZE_2NxnD: if (!pu) *h = s - q; else { *h = q; *oy = s - q; *addr = (n >> 1) + (n >> 3); } break;
+  case HMO_SIZE_nLx2N: if (!pu) *w = q; else { *w = s - q; *ox = q; *addr = n >> 4; } break;
+  case HMO_SIZE_nRx2N: if (!pu) *w = s - q; else { *w = q; *ox = s - q; *addr = (n >> 2) + (n >> 4); } break;
+  default: break;
+  }
 }
-static int pu_runs(const HmoCU *cu, int partSize, int pu, int start[2], int len[2])
-{
-  const int n = cu->nparts;
-  if (partSize == HMO_SIZE_2Nx2N) { start[0] = 0; len[0] = n; return 1; }
-  if (partSize == HMO_SIZE_2NxN) { start[0] = pu * (n >> 1); len[0] = n >> 1; return 1; }
-  if (partSize == HMO_SIZE_Nx2N) { start[0] = pu * (n >> 2); len[0] = n >> 2; start[1] = start[0] + (n >> 1); len[1] = n >> 2; return 2; }
-  start[0] = pu * (n >> 2); len[0] = n >> 2; return 1;
-}
-#define PU_FOR(cu, ps, pu, i) for (int r_[2], l_[2], nr_ = pu_runs(cu, ps, pu, r_, l_), k_ = 0; k_ < nr_; k_++) for (int i = r_[k_]; i < r_[k_] + l_[k_]; i++)
+/* the 4x4 partitions of a PU (what TComCUMvField::setAll / TComDataCU::setSubPart address for every partition shape,
+ * TComMotionInfo.cpp:128-303): all partitions of the CU whose position lies in the PU's rectangle */
+static int pu_has(const HmoCU *cu, int ox, int oy, int w, int h, int i)
+{ const int z = cu->zidx + i, lx = part_x(z) - (cu->x & 63), ly = part_y(z) - (cu->y & 63); return lx >= ox && lx < ox + w && ly >= oy && ly < oy + h; }
+#define PU_FOR(cu, ps, pu, i) for (int a_, ox_, oy_, w_, h_, i = (pu_geom(cu, ps, pu, &a_, &ox_, &oy_, &w_, &h_), 0); i < (cu)->nparts; i++) if (pu_has(cu, ox_, oy_, w_, h_, i))
 static void pu_set_motion(HmoCU *cu, int ps, int pu, HmoMv mv, int ref)
 { PU_FOR(cu, ps, pu, i) { cu->mv[i][0] = (int16_t)mv.x; cu->mv[i][1] = (int16_t)mv.y; cu->ref_idx[i] = (int8_t)ref; } }
 static void pu_set_mvd(HmoCU *cu, int ps, int pu, HmoMv d) { PU_FOR(cu, ps, pu, i) { cu->mvd[i][0] = (int16_t)d.x; cu->mvd[i][1] = (int16_t)d.y; } }
@@ -108,11 +111,11 @@ static int merge_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int 
   const int lbx = xP, lby = yP + h - 1, rtx = xP + w - 1, rty = yP;           /* corner partitions LB / RT; LT = (xP, yP) */
   int n = 0;
   HmoNb a1 = nb_motion(e, cu, xP - 1, yP + h - 1, lbx, lby);
-  const int okA1 = a1.avail && !(pu == 1 && partSize == HMO_SIZE_Nx2N) && a1.inter;
+  const int okA1 = a1.avail && !(pu == 1 && (partSize == HMO_SIZE_Nx2N || partSize == HMO_SIZE_nLx2N || partSize == HMO_SIZE_nRx2N)) && a1.inter;
   if (okA1) { mv[n] = a1.mv; ref[n] = a1.ref; n++; }
   if (n == maxc) return n;
   HmoNb b1 = nb_motion(e, cu, xP + w - 1, yP - 1, rtx, rty);
-  const int okB1 = b1.avail && !(pu == 1 && partSize == HMO_SIZE_2NxN) && b1.inter;
+  const int okB1 = b1.avail && !(pu == 1 && (partSize == HMO_SIZE_2NxN || partSize == HMO_SIZE_2NxnU || partSize == HMO_SIZE_2NxnD)) && b1.inter;
   if (okB1 && (!okA1 || !same_motion(&a1, &b1))) { mv[n] = b1.mv; ref[n] = b1.ref; n++; }
   if (n == maxc) return n;
   HmoNb b0 = nb_motion(e, cu, xP + w, yP - 1, rtx, rty);
@@ -464,25 +467,32 @@ static uint32_t inter_pred_error(HmoEnc *e, const HmoCU *cu, int partSize, int p
 }
 
 /* predInterSearch for a P slice with one reference picture */
-static void pred_inter_search(HmoEnc *e, HmoCU *cu, int partSize)
+static void pred_inter_search(HmoEnc *e, HmoCU *cu, int partSize, int useMrg)
 {
   const int d = cu->depth_cu, npu = pu_count(partSize);
+  const int normalMC = !(useMrg && cu_size(cu) > 8 && npu == 2);         /* AMP_MRG: merge estimation only (TEncSearch.cpp:3098-3103) */
   memset(e->pred_temp[d], 0, sizeof(HmoYuv));
   for (int pu = 0; pu < npu; pu++) {
     int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
     const uint32_t mbBits = (partSize == HMO_SIZE_2Nx2N || partSize == HMO_SIZE_NxN) ? 1 : 3;   /* xGetBlkBits, P slice */
     HmoMv cand[2], pred, mv; int mvpIdx;
     uint32_t bitsT = mbBits, costT = 0;
-    pred = estimate_mvp(e, cu, partSize, pu, cand, &mvpIdx);
-    bitsT += 1;                                                /* m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS] */
-    motion_estimation(e, cu, partSize, pu, pred, &mv, &bitsT, &costT);
-    check_best_mvp(e, mv, cand, &pred, &mvpIdx, &bitsT, &costT);
-    /* motion field of the PU: list 0 wins by construction (:3413-3427) */
-    HmoMv zero = { 0, 0 }, mvd; mvd.x = mv.x - pred.x; mvd.y = mv.y - pred.y;
-    pu_set_motion(cu, partSize, pu, mv, 0); pu_set_mvd(cu, partSize, pu, mvd); pu_set_dir(cu, partSize, pu, 1); pu_set_mvp(cu, partSize, pu, mvpIdx);
+    HmoMv zero = { 0, 0 };
+    mv = zero; pred = zero; mvpIdx = -1;
+    if (normalMC) {
+      pred = estimate_mvp(e, cu, partSize, pu, cand, &mvpIdx);
+      bitsT += 1;                                              /* m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS] */
+      motion_estimation(e, cu, partSize, pu, pred, &mv, &bitsT, &costT);
+      check_best_mvp(e, mv, cand, &pred, &mvpIdx, &bitsT, &costT);
+      /* motion field of the PU: list 0 wins by construction (:3413-3427) */
+      HmoMv mvd; mvd.x = mv.x - pred.x; mvd.y = mv.y - pred.y;
+      pu_set_motion(cu, partSize, pu, mv, 0); pu_set_mvd(cu, partSize, pu, mvd); pu_set_dir(cu, partSize, pu, 1); pu_set_mvp(cu, partSize, pu, mvpIdx);
+    } else {                                                   /* the cleared motion field (:3356-3363) */
+      pu_set_motion(cu, partSize, pu, zero, -1); pu_set_mvd(cu, partSize, pu, zero); pu_set_mvp(cu, partSize, pu, -1);
+    }
     pu_set_merge(cu, partSize, pu, 0, 0);
     if (partSize != HMO_SIZE_2Nx2N) {                          /* merge estimation of the PU (:3448-3498) */
-      const uint32_t meErr = inter_pred_error(e, cu, partSize, pu), meCost = meErr + motion_cost(e, bitsT);
+      const uint32_t meCost = normalMC ? inter_pred_error(e, cu, partSize, pu) + motion_cost(e, bitsT) : HMO_MAX_UINT;
       HmoMv mmv[5]; int mref[5];
       const int nc = merge_candidates(e, cu, partSize, pu, mmv, mref);
       uint32_t mrgCost = HMO_MAX_UINT; int mrgIdx = 0;
@@ -526,12 +536,16 @@ static void code_merge_index(HmoEnc *e, const HmoCU *cu, int part)
 /* codePartSize for an inter CU (AMP off) */
 static void code_part_size_inter(HmoEnc *e, const HmoCU *cu, int part, int depth)
 {
-  const int ps = cu->part_size[part];
+  const int ps = cu->part_size[part], amp = e->p.amp && depth < HMO_MAXDEPTH;       /* codePartSize, TEncSbac.cpp:436-520 */
   if (ps == HMO_SIZE_2Nx2N) { hmo_enc_bin(e, 1, HMO_CTX_PARTSIZE); return; }
   hmo_enc_bin(e, 0, HMO_CTX_PARTSIZE);
-  if (ps == HMO_SIZE_2NxN) { hmo_enc_bin(e, 1, HMO_CTX_PARTSIZE1); return; }
-  hmo_enc_bin(e, 0, HMO_CTX_PARTSIZE1);                                                                  /* Nx2N */
-  if (depth == HMO_MAXDEPTH && !((HMO_CTU >> depth) == 8)) hmo_enc_bin(e, 1, HMO_CTX_PARTSIZE1 + 1);
+  const int hor = ps == HMO_SIZE_2NxN || ps == HMO_SIZE_2NxnU || ps == HMO_SIZE_2NxnD;
+  hmo_enc_bin(e, hor, HMO_CTX_PARTSIZE1);
+  if (!hor && depth == HMO_MAXDEPTH && !((HMO_CTU >> depth) == 8)) hmo_enc_bin(e, 1, HMO_CTX_PARTSIZE1 + 1);
+  if (amp) {
+    if (ps == HMO_SIZE_2NxN || ps == HMO_SIZE_Nx2N) hmo_enc_bin(e, 1, HMO_CTX_PARTSIZE1 + 2);
+    else { hmo_enc_bin(e, 0, HMO_CTX_PARTSIZE1 + 2); hmo_enc_bins_ep(e, 1); }      /* 2NxnU / nLx2N: 0, 2NxnD / nRx2N: 1 */
+  }
 }
 static int ep_exgolomb_bins(uint32_t symbol, uint32_t count)                 /* xWriteEpExGolomb, TEncSbac.cpp:300-320 */
 { int n = 0; while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; } return n + 1 + (int)count; }
@@ -548,7 +562,8 @@ static void code_mvd(HmoEnc *e, int hor, int ver)
 static void code_pu_wise(HmoEnc *e, const HmoCU *cu, int part)
 {
   const int ps = cu->part_size[part], npu = pu_count(ps), n = HMO_NPART >> (2 * cu->depth[part]);
-  const int off = ps == HMO_SIZE_2NxN ? n >> 1 : (ps == HMO_SIZE_2Nx2N ? 0 : n >> 2);       /* g_auiPUOffset */
+  static const uint8_t k_off16[8] = { 0, 8, 4, 4, 2, 10, 1, 5 };                        /* g_auiPUOffset, TComRom.cpp; TEncEntropy.cpp:339 */
+  const int off = (k_off16[ps] * n) >> 4;
   for (int pu = 0, sp = part; pu < npu; pu++, sp += off) {
     hmo_enc_bin(e, cu->merge_flag[sp], HMO_CTX_MERGE_FLAG);
     if (cu->merge_flag[sp]) code_merge_index(e, cu, sp);
@@ -821,15 +836,15 @@ static void encode_res_and_calc_rd_inter_cu(HmoEnc *e, HmoCU *cu, int skipResidu
 
 /* xCheckRDCostInter */
 static int check_best_mode(HmoEnc *e, int d);
-static void check_rd_cost_inter(HmoEnc *e, int d, int partSize)
+static void check_rd_cost_inter(HmoEnc *e, int d, int partSize, int useMrg)
 {
   HmoCU *cu = e->temp[d];
   memset(cu->part_size, partSize, (size_t)cu->nparts);
   memset(cu->pred_mode, HMO_MODE_INTER, (size_t)cu->nparts);
-  if (e->trace) e->trace(e->trace_user, HMO_EV_INTER_BEGIN, d, partSize);
-  pred_inter_search(e, cu, partSize);
+  if (e->trace) e->trace(e->trace_user, HMO_EV_INTER_BEGIN, d, partSize | (useMrg << 4));
+  pred_inter_search(e, cu, partSize, useMrg);
   encode_res_and_calc_rd_inter_cu(e, cu, 0);
-  if (e->trace) e->trace(e->trace_user, HMO_EV_INTER_END, d, partSize);
+  if (e->trace) e->trace(e->trace_user, HMO_EV_INTER_END, d, partSize | (useMrg << 4));
   check_best_mode(e, d);
 }
 /* xCheckRDCostMerge2Nx2N (early skip detection off) */

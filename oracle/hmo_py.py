@@ -15,7 +15,7 @@ class Params(C.Structure):
                 ("strong_smoothing", C.c_int), ("lambda_", C.c_double), ("sqrt_lambda", C.c_double),
                 ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
-                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
+                ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("amp", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
                 ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint)]
 
 
@@ -59,6 +59,7 @@ class Yuv(C.Structure):
 
 
 SIZE_2Nx2N, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN = 0, 1, 2, 3
+SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N = 4, 5, 6, 7
 CI_CURR_BEST, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT = range(6)
 EV_INTRA_BEGIN, EV_INTRA_END, EV_INTER_BEGIN, EV_INTER_END, EV_MERGE_BEGIN, EV_MERGE_END = range(6)
 TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)

@@ -830,7 +830,7 @@ static void count_verify(HmoEnc *e, int d, int skipPredicted, int partitionTrue,
  * xCompressCU, TEncCu.cpp:460-1616.  Training: exhaustive; Verifying: exhaustive + TP/FP/TN/FN bookkeeping
  * (:1489-1497); Testing: Skip2Nx2N / TerminateCU pruning where the depth's switch is on (:951-996,1040,1143,1257,1446).
  * ---------------------------------------------------------------------------------- */
-static void compress_cu(HmoEnc *e, int d)
+static void compress_cu(HmoEnc *e, int d, int parentPartSize)
 {
   HmoCU *bestInit = e->best[d];
   const int x = bestInit->x, y = bestInit->y, zidx = bestInit->zidx, s = HMO_CTU >> d;
@@ -859,9 +859,25 @@ static void compress_cu(HmoEnc *e, int d)
     if (e->p.slice_type == HMO_SLICE_P) {                       /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
       check_rd_cost_merge_2nx2n(e, d);                          /* :774 */
       cu_init(e->temp[d], d, x, y, zidx);
-      check_rd_cost_inter(e, d, HMO_SIZE_2Nx2N); cu_init(e->temp[d], d, x, y, zidx);      /* :780 */
-      check_rd_cost_inter(e, d, HMO_SIZE_Nx2N); cu_init(e->temp[d], d, x, y, zidx);       /* :826 (inter NxN never: 8x8 CUs are excluded, :816) */
-      check_rd_cost_inter(e, d, HMO_SIZE_2NxN); cu_init(e->temp[d], d, x, y, zidx);       /* :835 */
+      check_rd_cost_inter(e, d, HMO_SIZE_2Nx2N, 0); cu_init(e->temp[d], d, x, y, zidx);      /* :780 */
+      check_rd_cost_inter(e, d, HMO_SIZE_Nx2N, 0); cu_init(e->temp[d], d, x, y, zidx);       /* :826 (inter NxN never: 8x8 CUs are excluded, :816) */
+      check_rd_cost_inter(e, d, HMO_SIZE_2NxN, 0); cu_init(e->temp[d], d, x, y, zidx);       /* :835 */
+      if (e->p.amp && d < HMO_MAXDEPTH) {                       /* AMP with AMP_ENC_SPEEDUP + AMP_MRG (:843-943); deriveTestModeAMP (:393-450) */
+        const HmoCU *bb = e->best[d];
+        const int bps = bb->part_size[0], par = parentPartSize;
+        int hor = 0, ver = 0, mhor = 0, mver = 0;
+        if (bps == HMO_SIZE_2NxN) hor = 1;
+        else if (bps == HMO_SIZE_Nx2N) ver = 1;
+        else if (bps == HMO_SIZE_2Nx2N && !bb->merge_flag[0] && !bb->skip[0]) hor = ver = 1;
+        if (par >= HMO_SIZE_2NxnU && par <= HMO_SIZE_nRx2N) mhor = mver = 1;
+        if (par == HMO_SIZE_NONE) { if (bps == HMO_SIZE_2NxN) mhor = 1; else if (bps == HMO_SIZE_Nx2N) mver = 1; }
+        if (bps == HMO_SIZE_2Nx2N && !bb->skip[0]) mhor = mver = 1;
+        if (s == 64) hor = ver = 0;
+        if (hor) { check_rd_cost_inter(e, d, HMO_SIZE_2NxnU, 0); cu_init(e->temp[d], d, x, y, zidx); check_rd_cost_inter(e, d, HMO_SIZE_2NxnD, 0); cu_init(e->temp[d], d, x, y, zidx); }
+        else if (mhor) { check_rd_cost_inter(e, d, HMO_SIZE_2NxnU, 1); cu_init(e->temp[d], d, x, y, zidx); check_rd_cost_inter(e, d, HMO_SIZE_2NxnD, 1); cu_init(e->temp[d], d, x, y, zidx); }
+        if (ver) { check_rd_cost_inter(e, d, HMO_SIZE_nLx2N, 0); cu_init(e->temp[d], d, x, y, zidx); check_rd_cost_inter(e, d, HMO_SIZE_nRx2N, 0); cu_init(e->temp[d], d, x, y, zidx); }
+        else if (mver) { check_rd_cost_inter(e, d, HMO_SIZE_nLx2N, 1); cu_init(e->temp[d], d, x, y, zidx); check_rd_cost_inter(e, d, HMO_SIZE_nRx2N, 1); cu_init(e->temp[d], d, x, y, zidx); }
+      }
       const HmoCU *b = e->best[d];                              /* intra only when the best inter candidate has a residual (:1033-1036) */
       tryIntra = b->cbf[0][0] != 0 || b->cbf[1][0] != 0 || b->cbf[2][0] != 0;
     }
@@ -892,7 +908,7 @@ static void compress_cu(HmoEnc *e, int d)
       if (sx < e->p.width && sy < e->p.height) {
         if (i == 0) e->slot[nd][CI_CURR_BEST] = e->slot[d][CI_CURR_BEST];
         else e->slot[nd][CI_CURR_BEST] = e->slot[nd][CI_NEXT_BEST];
-        compress_cu(e, nd);
+        compress_cu(e, nd, (boundary || e->best[d]->pred_mode[0] != HMO_MODE_INTER) ? HMO_SIZE_NONE : e->best[d]->part_size[0]);   /* eParentPartSize, :1341-1351 */
         cu_copy_part_from(e->temp[d], e->best[nd], i);
         /* xCopyYuv2Tmp */
         for (int yy = 0; yy < hs; yy++) memcpy(e->reco_temp[d]->y + ((i >> 1) * hs + yy) * 64 + (i & 1) * hs, e->reco_best[nd]->y + yy * 64, (size_t)hs);
@@ -1076,7 +1092,7 @@ void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
   int x = (ctuRsAddr % e->w_ctu) * HMO_CTU, y = (ctuRsAddr / e->w_ctu) * HMO_CTU;
   cu_init(e->best[0], 0, x, y, 0);
   cu_init(e->temp[0], 0, x, y, 0);
-  compress_cu(e, 0);
+  compress_cu(e, 0, HMO_SIZE_NONE);
   /* encodeCtu on [0][CI_CURR_BEST] (TEncSlice.cpp:1474-1487): replay the winner */
   {
     HmoCU *view = e->temp[0];

@@ -40,9 +40,13 @@ CASES = {      # name: (generator, width, height, base QP, seed, pictures, searc
     "tz_mixed_qp27": ("mixed", 136, 72, 27, 31, 3, 16),          # FastSearch 1, small window, partial CTUs
     "tmvp_mixed_qp30": ("mixed", 192, 128, 30, 9, 4, 16),          # TMVPMode 1 (temporal merge / AMVP candidate) + TZ search
     "tmvp_textured_qp35": ("textured", 136, 72, 35, 4, 4, 32),    # TMVP, partial CTUs (bottom-right candidates leaving the picture)
+    "amp_mixed_qp30": ("mixed", 192, 128, 30, 13, 3, 16),          # AMP 1 + TZ + TMVP: the closest to the reference's lowdelay_P cfg the path gets
+    "amp_shear_qp27": ("shear_textured", 192, 128, 27, 9, 3, 16),  # AMP + TZ on motion boundaries at CU quarters: asymmetric partitions win
+    "amp_textured_qp27": ("textured", 136, 72, 27, 6, 3, 32),     # AMP, partial CTUs, full search
 }
-FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1, "tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1}        # HM's FastSearch of a case (default 0 = full search)
-TMVP = {"tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1}           # TMVP on: the collocated picture is the reference picture
+FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1, "tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1, "amp_shear_qp27": 1}        # HM's FastSearch of a case (default 0 = full search)
+AMP = {"amp_mixed_qp30": 1, "amp_textured_qp27": 1, "amp_shear_qp27": 1}              # AMP on: asymmetric partitions at depths 0..2 (AMP_ENC_SPEEDUP + AMP_MRG selection)
+TMVP = {"tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1}           # TMVP on: the collocated picture is the reference picture
 
 
 def run_case(case, ref_factory, on_picture):
@@ -66,7 +70,7 @@ def run_case(case, ref_factory, on_picture):
             out.append((None, None))
         else:
             col = prev_ctus if TMVP.get(case, 0) else None
-            enc = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
+            enc = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
             ref = ref_factory(poc, f, qp, lam, prev, sr) if ref_factory else None
             if ref and col is not None:
                 ref.setup_col(col, poc)
@@ -97,6 +101,13 @@ def run_case(case, ref_factory, on_picture):
                     bad[0] += 1
                     if bad[0] <= 3:
                         print("MISMATCH poc", poc, "\n  ref   ", rec, "\n  oracle", mine)
+                        if os.environ.get("HMO_DEBUG_CTX") and ref and ev != hmo_py.EV_INTRA_END:
+                            a, fa = ref.coder(depth, hmo_py.CI_TEMP_BEST); b, fb = enc.test_slot(depth, hmo_py.CI_TEMP_BEST)
+                            d = [int(i) for i in st.O_SORTED if a[i] != b[i]]
+                            s0, f0 = enc.test_slot(depth, hmo_py.CI_CURR_BEST); print("   start", [int(s0[i]) for i in d], f0)
+                            print("   ctx differ at", d, [(int(a[i]), int(b[i])) for i in d], "frac", fa, fb)
+                            c = enc.test_cu(depth, best=False)
+                            print("   mvd", np.ctypeslib.as_array(c.mvd)[:c.nparts:4].tolist(), "mvp", np.ctypeslib.as_array(c.mvp_idx)[:c.nparts:4].tolist())
 
             enc.set_trace(on_event)
             enc.compress_frame()
@@ -116,7 +127,7 @@ def one(case):
     dbk, total_bad = {}, [0]
 
     def ref_factory(poc, f, qp, lam, prev, sr):
-        r = st.RefSearch(w, h, qp, f, search_range=sr, fast_search=FAST_SEARCH.get(case, 0))
+        r = st.RefSearch(w, h, qp, f, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
         r.setup_p(prev, lam)
         return r
 

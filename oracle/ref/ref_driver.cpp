@@ -553,8 +553,9 @@ void ref_set_ctu_inter(int ctu, const unsigned char *skip, const unsigned char *
   }
 }
 /* One inter candidate through the reference: the body of TEncCu::xCheckRDCostInter (TEncCu.cpp:2025-2062) */
-int ref_inter_cu(int ctu, int zidx, int depth, int partSize, RefCuOut *out)
+int ref_inter_cu(int ctu, int zidx, int depth, int partSizeArg, RefCuOut *out)
 {
+  const int partSize = partSizeArg & 15; const bool useMRG = ((partSizeArg >> 4) & 1) != 0;       /* bit 4: bUseMRG (AMP_MRG: merge estimation only) */
   TComDataCU *cu = position_cu(ctu, zidx, depth);
   entropy_to_goon();
   g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);
@@ -563,7 +564,7 @@ int ref_inter_cu(int ctu, int zidx, int depth, int partSize, RefCuOut *out)
   cu->setPredModeSubParts(MODE_INTER, 0, depth);
   cu->setChromaQpAdjSubParts(0, 0, depth);
   cu->setMergeAMP(true);
-  g_search->predInterSearch(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], false, false);
+  g_search->predInterSearch(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], false, useMRG);
   g_search->encodeResAndCalcRdInterCU(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yResiBest[depth], g_yReco[depth], false);
   cu->getTotalCost() = g_rd->calcRdCost(cu->getTotalBits(), cu->getTotalDistortion());
   read_cu(cu, depth, out);
@@ -602,6 +603,12 @@ int ref_merge_cu(int ctu, int zidx, int depth, int cand, int noResidual, RefCuOu
 
 /* RDOQ / RDOQTS switches of the quantiser (TComTrQuant::init, TEncTop.cpp; xQuant reads them, TComTrQuant.cpp:1145-1147)
  * and the slice type, which selects the rounding offset of the plain quantiser (:1199) */
+/* AMP on / off in the SPS (TEncTop::xInitSPS: setUseAMP): changes the part-size syntax and admits the asymmetric sizes */
+void ref_set_amp(int on)
+{
+  TComSPS *sps = const_cast<TComSPS *>(g_slice->getSPS());
+  sps->setUseAMP(on != 0); g_sps.setUseAMP(on != 0);
+}
 void ref_set_rdoq(int rdoq, int rdoqTS) { g_trq->m_useRDOQ = rdoq != 0; g_trq->m_useRDOQTS = rdoqTS != 0; }
 void ref_set_slice_type(int isP) { g_slice->setSliceType(isP ? P_SLICE : I_SLICE); }
 

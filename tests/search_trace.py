@@ -106,10 +106,19 @@ def ifmt(rec):
 
 def moving_frame(synth, gen, w, h, seed, i, shift=(3, 1)):
     """picture i of the synthetic lowdelay_P clip: the generator's picture shifted by `shift`
-    samples per picture, plus fresh +-2 noise on luma"""
+    samples per picture, plus fresh +-2 noise on luma.  A generator name "shear_<gen>" moves bands of the picture with a
+    second vector (rows 48..63 of every 64 in the left half, columns 0..15 of every 64 in the right half): motion
+    boundaries at quarter positions of the CUs, the case asymmetric partitions exist for."""
+    if gen.startswith("shear_"):
+        a = moving_frame(synth, gen[6:], w, h, seed, i, shift)
+        b = moving_frame(synth, gen[6:], w, h, seed + 1, i, (-shift[1] - 1, shift[0]))
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = np.where(xx < w // 2, (yy % 64) >= 48, (xx % 64) < 16)
+        mc = m[::2, ::2]
+        return (np.where(m, b[0], a[0]), np.where(mc, b[1], a[1]), np.where(mc, b[2], a[2]))
     Y, U, V = getattr(synth, gen)(w + 32, h + 32, seed=seed)
     dx, dy = (shift[0] * i) % 32, (shift[1] * i) % 32
-    dx, dy = dx & ~1, dy & ~1 if False else dy                      # luma shift free; chroma uses the halved shift
+    dx = dx & ~1                                                     # horizontal shift even (chroma uses the halved shift); vertical free
     rng = np.random.default_rng(1000 + 17 * seed + i)
     Yc = Y[dy:dy + h, dx:dx + w].astype(np.int16) + rng.integers(-2, 3, (h, w))
     cx, cy = dx // 2, dy // 2
@@ -137,7 +146,7 @@ class RefCuOut(C.Structure):
 class RefSearch:
     """The reference's TEncSearch behind ref_driver.cpp, fed with oracle states."""
 
-    def __init__(self, w, h, qp, org, search_range=64, fast_search=0):
+    def __init__(self, w, h, qp, org, search_range=64, fast_search=0, amp=0):
         self.L = L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhmleaf.so"))
         L.ref_coder_get.restype = C.c_ulonglong
         L.ref_coder_set.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ulonglong]
@@ -146,6 +155,7 @@ class RefSearch:
         self.n_ctu = L.ref_setup(w, h, qp)
         assert L.ref_search_setup(search_range, fast_search, 1, 1, 1) == 0
         self.fast_search = fast_search
+        L.ref_set_amp(1 if amp else 0)
         self.is_p = False
         for c in range(3):
             L.ref_set_org(c, np.ascontiguousarray(org[c]).ctypes.data_as(C.c_void_p))
