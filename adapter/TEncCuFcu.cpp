@@ -106,7 +106,7 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     fp.fast_merge_decision = cfg->getUseFastDecisionForMerge(); fp.max_merge_cand = slice->getMaxNumMergeCand();
     fp.fast_search = cfg->getFastSearch() ? 1 : 0;
     if (slice->getEnableTMVPFlag()) { fprintf(stderr, "TEncCuFcu: run HM with TMVPMode 0 (the collocated motion field is not uploaded by this adapter yet)\n"); exit(1); }
-    if (slice->getSPS()->getUseAMP()) { fprintf(stderr, "TEncCuFcu: run HM with AMP 0 (asymmetric partitions are not behind the ABI)\n"); exit(1); }
+    fp.amp = slice->getSPS()->getUseAMP() ? 1 : 0;              /* part sizes 4..7 come back with HM's own PartSize values */
   }
   int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
   if (rc != FCU_OK) die("fcu_chain_begin", rc);

@@ -109,6 +109,10 @@ __device__ static inline DbkPart dbk_part(const fcu_ctu_out *out, int w_ctu, int
   if (ps == SIZE_NONE || pos == 0) return r;
   if ((pos & (tu - 1)) == 0) r.flag = 1;                                   /* transform-unit / CU edge */
   else if ((pos & (cu - 1)) == (cu >> 1) && (ps == SIZE_NxN || (DIR == 0 ? ps == SIZE_Nx2N : ps == SIZE_2NxN))) r.flag = 2;   /* PU edge only */
+  /* asymmetric partitions: the edge at a quarter of the CU (xSetEdgefilterPU, TComLoopFilter.cpp:331-350); only 32x32 and
+   * 64x64 CUs put it on the 8-sample grid the filter visits */
+  else if ((pos & (cu - 1)) == (cu >> 2) && (DIR == 0 ? ps == SIZE_nLx2N : ps == SIZE_2NxnU)) r.flag = 2;
+  else if ((pos & (cu - 1)) == cu - (cu >> 2) && (DIR == 0 ? ps == SIZE_nRx2N : ps == SIZE_2NxnD)) r.flag = 2;
   if (!r.flag) return r;
   /* boundary strength against the partition on the P side */
   const int px4 = DIR == 0 ? x4 - 1 : x4, py4 = DIR == 0 ? y4 : y4 - 1;

@@ -163,7 +163,7 @@ namespace fcu {
 
 /* ---- constants ------------------------------------------------------------------------ */
 enum { CTU = 64, MAXDEPTH = 3, NPART = 256, LOG2_MAXTU = 5, LOG2_MINTU = 2, TU_MAXDEPTH_INTRA = 3 };
-enum { SIZE_2Nx2N = 0, SIZE_2NxN = 1, SIZE_Nx2N = 2, SIZE_NxN = 3, SIZE_NONE = 8, MODE_INTER = 0, MODE_INTRA = 1, MODE_NONE = 2 };
+enum { SIZE_2Nx2N = 0, SIZE_2NxN = 1, SIZE_Nx2N = 2, SIZE_NxN = 3, SIZE_2NxnU = 4, SIZE_2NxnD = 5, SIZE_nLx2N = 6, SIZE_nRx2N = 7, SIZE_NONE = 8, MODE_INTER = 0, MODE_INTRA = 1, MODE_NONE = 2 };
 enum { SLICE_I = 0, SLICE_P = 1 };
 enum { PLANAR = 0, DC = 1, HOR = 10, VER = 26, DM_CHROMA = 36 };
 /* context layout (counts: TLibCommon/ContextTables.h:49-161) */
@@ -191,6 +191,7 @@ struct Params {
   /* P slices (BASELINE configs[4]) */
   int search_range, fast_enc, had_me, fdm, max_merge_cand, fast_search;
   int tmvp;                    /* TMVPMode: temporal merge / AMVP candidate from Chain::col */
+  int amp;                     /* asymmetric motion partitions (AMP with AMP_ENC_SPEEDUP + AMP_MRG, TEncCu.cpp:381-450,836-943) */
   int rdoq, rdoq_ts;           /* RDOQ / RDOQTS: 0 = the plain quantiser of xQuant (quant_plain) for blocks without / with transform skip */
   uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
 };
@@ -299,6 +300,7 @@ struct Shared {
   };
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
+  int8_t par_ps[4];                                /* eParentPartSize of the CU being compressed at each depth (SIZE_NONE: intra / none) */
   /* PU / TU mailbox written by serial blocks */
   union {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
@@ -2663,13 +2665,13 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_intra(int d, int partSize)
 }
 
 /* xCheckRDCostInter, TEncCu.cpp:2025-2062 */
-FCU_DEV FCU_NOINLINE void check_rd_cost_inter(int d, int partSize)
+FCU_DEV FCU_NOINLINE void check_rd_cost_inter(int d, int partSize, int useMrg)
 {
-  const Env E = env_get(); d = FCU_UNI(d); partSize = FCU_UNI(partSize);
+  const Env E = env_get(); d = FCU_UNI(d); partSize = FCU_UNI(partSize); useMrg = FCU_UNI(useMrg);
   CuObj *cu = cu_temp(E, d);
   const int n = cu->nparts;
   FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTER; } }
-  pred_inter_search(cu, partSize);
+  pred_inter_search(cu, partSize, useMrg);
   encode_res_and_calc_rd_inter_cu(cu, 0);
   check_best_mode(d);
 }
@@ -2758,9 +2760,29 @@ FCU_DEV FCU_NOINLINE void compress_cu()
     if (P.slice_type == SLICE_P) {                           /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
       check_rd_cost_merge_2nx2n(D);
       cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_2Nx2N); cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_Nx2N); cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_2NxN); cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_2Nx2N, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_Nx2N, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
+      check_rd_cost_inter(D, SIZE_2NxN, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
+      if (P.amp && D < MAXDEPTH) {                             /* AMP with AMP_ENC_SPEEDUP + AMP_MRG (:836-943); deriveTestModeAMP (:381-430) */
+        const CuObj *bb = cu_best(E, D);
+        const int bps = FCU_UNI((int)bb->part_size[0]), bmrg = FCU_UNI((int)bb->merge_flag[0]), bskip = FCU_UNI((int)bb->skip[0]), par = FCU_UNI((int)g_S.par_ps[D]);
+        int hor = 0, ver = 0, mhor = 0, mver = 0;
+        if (bps == SIZE_2NxN) hor = 1;
+        else if (bps == SIZE_Nx2N) ver = 1;
+        else if (bps == SIZE_2Nx2N && !bmrg && !bskip) hor = ver = 1;
+        if (par >= SIZE_2NxnU && par <= SIZE_nRx2N) mhor = mver = 1;
+        if (par == SIZE_NONE) { if (bps == SIZE_2NxN) mhor = 1; else if (bps == SIZE_Nx2N) mver = 1; }
+        if (bps == SIZE_2Nx2N && !bskip) mhor = mver = 1;
+        if (s == 64) hor = ver = 0;
+        if (hor || mhor) {
+          check_rd_cost_inter(D, SIZE_2NxnU, !hor); cu_init(cu_temp(E, D), D, x, y, zidx);
+          check_rd_cost_inter(D, SIZE_2NxnD, !hor); cu_init(cu_temp(E, D), D, x, y, zidx);
+        }
+        if (ver || mver) {
+          check_rd_cost_inter(D, SIZE_nLx2N, !ver); cu_init(cu_temp(E, D), D, x, y, zidx);
+          check_rd_cost_inter(D, SIZE_nRx2N, !ver); cu_init(cu_temp(E, D), D, x, y, zidx);
+        }
+      }
       const CuObj *b = cu_best(E, D);                          /* intra only when the best inter candidate has a residual (:1033-1036) */
       tryIntra = FCU_UNI((int)(b->cbf[0][0] | b->cbf[1][0] | b->cbf[2][0])) != 0;
     }
@@ -2786,6 +2808,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
   if constexpr (D < MAXDEPTH) {
    if (!earlyTerminate) {                                    /* bSubBranch = false, TEncCu.cpp:1257-1260 */
     const int nd = D + 1, hs = s >> 1, qn = NPART >> (2 * nd);
+    FCU_SERIAL { const CuObj *b = cu_best(E, D); g_S.par_ps[nd] = (int8_t)((boundary || b->pred_mode[0] != MODE_INTER) ? SIZE_NONE : b->part_size[0]); }   /* eParentPartSize, :1355-1363 */
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
       cu_init(&G->cu[nd][0], nd, sx, sy, zidx + i * qn);
@@ -2908,7 +2931,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
     for (int i = lane; i < 4096; i += 64) out->coeff_y[i] = 0;
     for (int i = lane; i < 1024; i += 64) { out->coeff_cb[i] = 0; out->coeff_cr[i] = 0; }
     cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
-    if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
+    if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; g_S.par_ps[d] = SIZE_NONE; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
   }
   cu_init(&G->cu[0][0], 0, x, y, 0);
   cu_init(&G->cu[0][1], 0, x, y, 0);

@@ -14,7 +14,7 @@ inline void fill_params(Params &p, int width, int height, const fcu_frame_params
 {
   p.width = width; p.height = height; p.qp = fp.qp; p.slice_ctus = fp.slice_ctus;
   p.slice_type = fp.slice_type; p.search_range = fp.search_range; p.fast_enc = fp.fast_enc; p.had_me = fp.hadamard_me;
-  p.fast_search = fp.fast_search; p.rdoq = fp.rdoq; p.rdoq_ts = fp.rdoq_ts; p.tmvp = fp.tmvp;
+  p.fast_search = fp.fast_search; p.rdoq = fp.rdoq; p.rdoq_ts = fp.rdoq_ts; p.tmvp = fp.tmvp; p.amp = fp.amp != 0;
   p.fdm = fp.fast_merge_decision; p.max_merge_cand = fp.max_merge_cand > 0 ? (fp.max_merge_cand > 5 ? 5 : fp.max_merge_cand) : 5;
   p.transform_skip = fp.transform_skip; p.ts_fast = fp.transform_skip_fast;
   p.sign_hiding = fp.sign_hiding; p.strong_smoothing = fp.strong_intra_smoothing;
@@ -60,7 +60,7 @@ inline void default_frame_params(fcu_frame_params &fp, int qp)
 {
   memset(&fp, 0, sizeof(fp));
   fp.qp = qp; fp.slice_ctus = 0; fp.transform_skip = 1; fp.transform_skip_fast = 1; fp.sign_hiding = 1; fp.strong_intra_smoothing = 1;
-  fp.slice_type = FCU_SLICE_I; fp.search_range = 64; fp.fast_enc = 1; fp.hadamard_me = 1; fp.fast_merge_decision = 1; fp.max_merge_cand = 5; fp.fast_search = 0; fp.tmvp = 0; fp.rdoq = 1; fp.rdoq_ts = 1;
+  fp.slice_type = FCU_SLICE_I; fp.search_range = 64; fp.fast_enc = 1; fp.hadamard_me = 1; fp.fast_merge_decision = 1; fp.max_merge_cand = 5; fp.fast_search = 0; fp.tmvp = 0; fp.rdoq = 1; fp.rdoq_ts = 1; fp.amp = 0;
 }
 /* TEncSlice::initEncSlice for HM's lowdelay_P GOP table (GOPSize 4): slice type, QP = base + offset, lambda =
  * QPFactor * 2^((QP-12)/3), x Clip3(2, 4, (QP-12)/6) at temporal depth > 0 (POC % 4 != 0); the I picture's factor is

@@ -28,6 +28,13 @@ FCU_DEV Pu pu_geom(int depth, int ps, int pu)                  /* getPartIndexAn
   if (ps == SIZE_2NxN) { g.h = s >> 1; if (pu) { g.addr = n >> 1; g.oy = s >> 1; } }
   else if (ps == SIZE_Nx2N) { g.w = s >> 1; if (pu) { g.addr = n >> 2; g.ox = s >> 1; } }
   else if (ps == SIZE_NxN) { g.w = g.h = s >> 1; g.addr = pu * (n >> 2); g.ox = (pu & 1) * (s >> 1); g.oy = (pu >> 1) * (s >> 1); }
+  else if (ps >= SIZE_2NxnU && ps <= SIZE_nRx2N) {             /* asymmetric: a quarter and three quarters (TComDataCU.cpp:2165-2240) */
+    const int q = s >> 2;
+    if (ps == SIZE_2NxnU) { if (!pu) g.h = q; else { g.h = s - q; g.oy = q; g.addr = n >> 3; } }
+    else if (ps == SIZE_2NxnD) { if (!pu) g.h = s - q; else { g.h = q; g.oy = s - q; g.addr = (n >> 1) + (n >> 3); } }
+    else if (ps == SIZE_nLx2N) { if (!pu) g.w = q; else { g.w = s - q; g.ox = q; g.addr = n >> 4; } }
+    else { if (!pu) g.w = s - q; else { g.w = q; g.ox = s - q; g.addr = (n >> 2) + (n >> 4); } }
+  }
   return g;
 }
 /* does partition i (relative to the CU, n partitions) belong to prediction unit pu?  (TComCUMvField::setAll / setSubPart) */
@@ -36,7 +43,14 @@ FCU_DEV int pu_covers(int n, int ps, int pu, int i)
   if (ps == SIZE_2Nx2N) return 1;
   if (ps == SIZE_2NxN) return (i >= (n >> 1)) == (pu != 0);
   if (ps == SIZE_Nx2N) return ((i / (n >> 2)) & 1) == pu;
-  return i / (n >> 2) == pu;
+  if (ps == SIZE_NxN) return i / (n >> 2) == pu;
+  /* asymmetric: position of partition i inside the CU (a CU is aligned to its size, so the z-order index is local) against
+   * the quarter line; n partitions = (s / 4)^2 */
+  const int lx = part_x(i), ly = part_y(i), s = n == 256 ? 64 : (n == 64 ? 32 : (n == 16 ? 16 : 8)), q = s >> 2;
+  if (ps == SIZE_2NxnU) return (ly >= q) == (pu != 0);
+  if (ps == SIZE_2NxnD) return (ly >= s - q) == (pu != 0);
+  if (ps == SIZE_nLx2N) return (lx >= q) == (pu != 0);
+  return (lx >= s - q) == (pu != 0);
 }
 /* motion fields of one PU: all lanes */
 FCU_DEV void pu_set_motion(CuObj *cu, int ps, int pu, int lane, int mvx, int mvy, int ref)
@@ -107,10 +121,10 @@ FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
   int n = 0;
 #define FCU_ADD_MRG(nb) do { g_S.mrg_mv[n][0] = (nb).mvx; g_S.mrg_mv[n][1] = (nb).mvy; g_S.mrg_ref[n] = (nb).ref; n++; } while (0)
   const Nb a1 = nb_motion(E, cu, xP - 1, yP + h - 1, lbx, lby);
-  const int okA1 = a1.avail && !(pu == 1 && ps == SIZE_Nx2N) && a1.inter;
+  const int okA1 = a1.avail && !(pu == 1 && (ps == SIZE_Nx2N || ps == SIZE_nLx2N || ps == SIZE_nRx2N)) && a1.inter;
   if (okA1) FCU_ADD_MRG(a1);
   const Nb b1 = nb_motion(E, cu, xP + w - 1, yP - 1, rtx, rty);
-  const int okB1 = b1.avail && !(pu == 1 && ps == SIZE_2NxN) && b1.inter;
+  const int okB1 = b1.avail && !(pu == 1 && (ps == SIZE_2NxN || ps == SIZE_2NxnU || ps == SIZE_2NxnD)) && b1.inter;
   if (n < maxc && okB1 && (!okA1 || !same_motion(a1, b1))) FCU_ADD_MRG(b1);
   const Nb b0 = nb_motion(E, cu, xP + w, yP - 1, rtx, rty);
   const int okB0 = b0.avail && b0.inter;
@@ -526,18 +540,23 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
 }
 
 /* ---- predInterSearch (P slice, one reference picture): motion of every PU of the CU + its prediction in predt[d] */
-FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps)
+FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps);
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); useMrg = FCU_UNI(useMrg);
   const Params &P = E.C->p; Scratch *G = E.G;
   const int d = cu->depth_cu, npu = pu_count(ps);
+  const int normalMC = !(useMrg && (CTU >> d) > 8 && npu == 2);   /* AMP_MRG: merge estimation only (TEncSearch.cpp:3098-3103) */
   for (int pu = 0; pu < npu; pu++) {
     const uint32_t mbBits = (ps == SIZE_2Nx2N || ps == SIZE_NxN) ? 1 : 3;      /* xGetBlkBits, P slice */
+    int mvx = 0, mvy = 0; uint32_t bitsT = mbBits;
+    if (!normalMC) {                                         /* the cleared motion field (:3356-3363) */
+      FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, 0, 0, -1); pu_set_info(cu, ps, pu, lane, 0, 0, 0, 0, -1); }
+    } else {
     int mvpIdx = estimate_mvp(cu, ps, pu);
     int predx = FCU_UNI(g_S.amvp[mvpIdx][0]), predy = FCU_UNI(g_S.amvp[mvpIdx][1]);
     motion_estimation(cu, ps, pu, predx, predy, mbBits + 1);
-    const int mvx = FCU_UNI(g_S.me_out[0]), mvy = FCU_UNI(g_S.me_out[1]);
-    uint32_t bitsT = FCU_UNI(g_S.acc[12]), costT = FCU_UNI(g_S.acc[13]);
+    mvx = FCU_UNI(g_S.me_out[0]); mvy = FCU_UNI(g_S.me_out[1]);
+    bitsT = FCU_UNI(g_S.acc[12]); uint32_t costT = FCU_UNI(g_S.acc[13]);
     {                                                        /* xCheckBestMVP */
       const int orgBits = (int)mv_bits(mvx, mvy, predx, predy, 0) + 1;
       int bestBits = orgBits, bestIdx = mvpIdx;
@@ -554,8 +573,9 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps)
       }
     }
     FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); pu_set_info(cu, ps, pu, lane, 0, 0, mvx - predx, mvy - predy, mvpIdx); }
+    }
     if (ps != SIZE_2Nx2N) {                                  /* merge estimation of the PU (TEncSearch.cpp:3448-3498) */
-      const uint32_t meCost = inter_pred_error(cu, ps, pu) + motion_cost(P, bitsT);
+      const uint32_t meCost = normalMC ? inter_pred_error(cu, ps, pu) + motion_cost(P, bitsT) : 0xffffffffu;
       FCU_SERIAL merge_candidates(cu, ps, pu);
       uint32_t mrgCost = 0xffffffffu; int mrgIdx = 0;
       const int nc = P.max_merge_cand;
@@ -591,14 +611,18 @@ FCU_DEV void code_merge_index(const Env E, int c, const CuObj *cu, int part)
   const int idx = cu->merge_idx[part], n = E.C->p.max_merge_cand;
   for (int ui = 0; ui < n - 1; ui++) { const int sym = ui == idx ? 0 : 1; if (ui == 0) cab_bin(c, sym, CTX_MERGE_IDX); else cab_ep(c, 1); if (!sym) break; }
 }
-FCU_DEV void code_part_size_inter(int c, const CuObj *cu, int part, int depth)              /* TEncSbac.cpp:436-520, AMP off */
+FCU_DEV void code_part_size_inter(const Env E, int c, const CuObj *cu, int part, int depth)              /* TEncSbac.cpp:436-520 */
 {
-  const int ps = cu->part_size[part];
+  const int ps = cu->part_size[part], amp = E.C->p.amp && depth < MAXDEPTH;
   if (ps == SIZE_2Nx2N) { cab_bin(c, 1, CTX_PARTSIZE); return; }
   cab_bin(c, 0, CTX_PARTSIZE);
-  if (ps == SIZE_2NxN) { cab_bin(c, 1, CTX_PARTSIZE1); return; }
-  cab_bin(c, 0, CTX_PARTSIZE1);
-  if (depth == MAXDEPTH && !((CTU >> depth) == 8)) cab_bin(c, 1, CTX_PARTSIZE1 + 1);
+  const int hor = ps == SIZE_2NxN || ps == SIZE_2NxnU || ps == SIZE_2NxnD;
+  cab_bin(c, hor, CTX_PARTSIZE1);
+  if (!hor && depth == MAXDEPTH && !((CTU >> depth) == 8)) cab_bin(c, 1, CTX_PARTSIZE1 + 1);
+  if (amp) {                                                   /* fourth part_mode context, then one bypass bin: 2NxnU / nLx2N 0, 2NxnD / nRx2N 1 */
+    if (ps == SIZE_2NxN || ps == SIZE_Nx2N) cab_bin(c, 1, CTX_PARTSIZE1 + 2);
+    else { cab_bin(c, 0, CTX_PARTSIZE1 + 2); cab_ep(c, 1); }
+  }
 }
 FCU_DEV int ep_exgolomb_bins(uint32_t symbol, uint32_t count) { int n = 0; while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; } return n + 1 + (int)count; }
 FCU_DEV void code_mvd(int c, int hor, int ver)                                             /* TEncSbac.cpp:780-830 */
@@ -613,7 +637,7 @@ FCU_DEV void code_mvd(int c, int hor, int ver)                                  
 FCU_DEV void code_pu_wise(const Env E, int c, const CuObj *cu, int part)                    /* TEncEntropy.cpp:456-507 */
 {
   const int ps = cu->part_size[part], npu = pu_count(ps), n = NPART >> (2 * cu->depth[part]);
-  const int off = ps == SIZE_2NxN ? n >> 1 : (ps == SIZE_2Nx2N ? 0 : n >> 2);
+  const int off = (((0x51a24480u >> (4 * ps)) & 15) * n) >> 4;   /* g_auiPUOffset {0, 8, 4, 4, 2, 10, 1, 5} sixteenths of the CU (TEncEntropy.cpp:339) */
   for (int pu = 0, sp = part; pu < npu; pu++, sp += off) {
     cab_bin(c, cu->merge_flag[sp], CTX_MERGE_FLAG);
     if (cu->merge_flag[sp]) code_merge_index(E, c, cu, sp);
@@ -667,7 +691,7 @@ FCU_DEV void encode_cu_syntax_inter(const Env E, int c, const CuObj *cu, int cuP
   code_skip_flag(E, c, cu, cuPart);
   if (cu->skip[cuPart]) { code_merge_index(E, c, cu, cuPart); return; }
   code_pred_mode(c, cu, cuPart);
-  code_part_size_inter(c, cu, cuPart, depth);
+  code_part_size_inter(E, c, cu, cuPart, depth);
   code_pu_wise(E, c, cu, cuPart);
   if (!(cu->merge_flag[cuPart] && cu->part_size[cuPart] == SIZE_2Nx2N)) cab_bin(c, qt_root_cbf(cu, cuPart), CTX_ROOT_CBF);
   if (!qt_root_cbf(cu, cuPart)) return;

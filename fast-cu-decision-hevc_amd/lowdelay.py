@@ -19,7 +19,7 @@ class LowDelayPDecider:
     """`n_clips` clips of width x height decided picture by picture on one GPU.
     slice_ctus: CTUs per slice (HM SliceMode 1); None = one slice per picture (the reference configuration)."""
 
-    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, tmvp=False, fast_search=1, device=0):
+    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, tmvp=False, fast_search=1, amp=False, device=0):
         self.width, self.height, self.base_qp, self.n_clips, self.search_range = width, height, base_qp, n_clips, search_range
         n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
         self.slice_ctus = slice_ctus if slice_ctus else n_ctu
@@ -27,6 +27,7 @@ class LowDelayPDecider:
         self.eng = _engine.CuEngine(width, height, max_chains=n_clips * self.n_slices, device=device)
         self.do_deblock = deblock
         self.tmvp, self.fast_search = tmvp, fast_search    # TMVPMode / FastSearch of the reference cfg (TZ search by default)
+        self.amp = amp                                   # AMP of the reference cfg (asymmetric motion partitions)
         self.col = [None] * n_clips                      # fcu_ctu_out array of each clip's previous picture (TMVP motion field)
         self.do_sao = sao                                # SAO 1 of the reference's cfg; off by default: the loop-filter goldens stop at deblocking
         self.sao_rate = [_engine.SaoRate() for _ in range(n_clips)]      # m_saoDisabledRate per clip
@@ -38,6 +39,7 @@ class LowDelayPDecider:
         fp.search_range = self.search_range
         fp.fast_search = self.fast_search
         fp.tmvp = 1 if (self.tmvp and poc > 0) else 0
+        fp.amp = 1 if self.amp else 0
         return fp
 
     def decide_picture(self, frames):

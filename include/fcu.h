@@ -96,6 +96,8 @@ typedef struct fcu_frame_params {
                                     (collocated_from_l0, collocated_ref_idx 0); needs fcu_chain_set_collocated                */
   int rdoq, rdoq_ts;             /* RDOQ / RDOQTS (fcu_default_frame_params: 1, 1): 0 = TComTrQuant::xQuant's plain quantiser with
                                     signBitHidingHDQ for blocks without / with transform skip */
+  int amp;                       /* AMP: asymmetric motion partitions 2NxnU / 2NxnD / nLx2N / nRx2N at CU sizes 64..16, selected as
+                                    HM does with AMP_ENC_SPEEDUP + AMP_MRG (TEncCu.cpp:381-450,836-943); part_size 4..7 in fcu_ctu_out */
 } fcu_frame_params;
 enum { FCU_SLICE_I = 0, FCU_SLICE_P = 1 };
 #define FCU_REF_MARGIN_LUMA 80   /* border of a padded reference plane: g_uiMaxCUWidth + 16 (TComPic::create); chroma: 40 */

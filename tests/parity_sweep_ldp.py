@@ -56,6 +56,8 @@ def main():
                      strong_intra_smoothing=int(rng.integers(0, 2)))
         sao = int(rng.random() < 0.6)
         tmvp = int(rng.random() < 0.5)
+        amp = int(rng.random() < 0.5)
+        shear = int(rng.random() < 0.5)                      # bands of the picture move the other way: motion boundaries at CU quarters
         boff, toff = int(rng.integers(-2, 3)), int(rng.integers(-2, 3))
         big = getattr(pkg.synth, gen)(w + 64, h + 64, seed=seed)
         eng = pkg.CuEngine(w, h, max_chains=1)
@@ -68,13 +70,22 @@ def main():
             Y = np.clip(big[0][oy:oy + h, ox:ox + w].astype(np.int16) + nz, 0, 255).astype(np.uint8)
             U = np.ascontiguousarray(big[1][oy // 2:oy // 2 + h // 2, ox // 2:ox // 2 + w // 2])
             V = np.ascontiguousarray(big[2][oy // 2:oy // 2 + h // 2, ox // 2:ox // 2 + w // 2])
-            f = (np.ascontiguousarray(Y), U, V)
+            if shear:
+                ox2, oy2 = 32 - dxy[1] * poc, 32 + dxy[0] * poc
+                yy, xx = np.mgrid[0:h, 0:w]
+                m = np.where(xx < w // 2, (yy % 64) >= 48, (xx % 64) < 16)
+                mc = m[::2, ::2]
+                Y = np.where(m, np.clip(big[0][oy2:oy2 + h, ox2:ox2 + w].astype(np.int16) + nz, 0, 255).astype(np.uint8), Y)
+                U = np.where(mc, big[1][oy2 // 2:oy2 // 2 + h // 2, ox2 // 2:ox2 // 2 + w // 2], U)
+                V = np.where(mc, big[2][oy2 // 2:oy2 // 2 + h // 2, ox2 // 2:ox2 // 2 + w // 2], V)
+            f = (np.ascontiguousarray(Y), np.ascontiguousarray(U), np.ascontiguousarray(V))
             fp = pkg.engine.ldp_slice(base_qp, poc)
             stype, qp, lam = hmo_py.ldp_slice(poc, base_qp)
             if not (0 <= qp <= 51):
                 break
             fp.search_range, fp.fast_search, fp.rdoq, fp.rdoq_ts = sr, fast, rdoq, rdoq_ts
             fp.tmvp = 1 if (tmvp and poc) else 0
+            fp.amp = amp
             for k, v in tools.items():
                 setattr(fp, k, v)
             eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, ref=pad, col=prev_out if fp.tmvp else None)
@@ -83,7 +94,7 @@ def main():
             ot = dict(tools)
             ot["strong_smoothing"] = ot.pop("strong_intra_smoothing")
             kw = dict(slice_ctus=sl, lambda_override=lam, rdoq=rdoq, rdoq_ts=rdoq_ts, **ot)
-            o = hmo_py.Encoder(*f, qp, **kw) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, search_range=sr, fast_search=fast, **kw)
+            o = hmo_py.Encoder(*f, qp, **kw) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, search_range=sr, fast_search=fast, amp=amp, **kw)
             o.compress_frame()
             for a in range(n_ctu):
                 got, want = eng.ctu_out(0, a), o.ctu_arrays(a)
@@ -121,7 +132,7 @@ def main():
         eng.destroy()
         bad += bool(diffs)
         print(f"clip {clip:3d} {gen:8s} {w}x{h} qp{base_qp:2d} pics {n_pic} motion {dxy} slice_ctus {sl} sr {sr} fast {fast} rdoq {rdoq}/{rdoq_ts} "
-              f"tools {list(tools.values())} sao {sao} tmvp {tmvp} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
+              f"tools {list(tools.values())} sao {sao} tmvp {tmvp} amp {amp} shear {shear} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
     print(f"{args.clips - bad} of {args.clips} clips identical")
     sys.exit(1 if bad else 0)
 

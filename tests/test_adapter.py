@@ -52,16 +52,17 @@ def test_intra_ctus_through_the_adapter_into_the_reference_coder(built, pkg, pat
         assert np.array_equal(stt[:n], g["states"][a]), (a, "context states")
 
 
-@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr", [("mixed", 136, 72, 27, 3, 8), ("textured", 128, 64, 35, 3, 16)])
-def test_p_ctus_through_the_adapter_into_the_reference_coder(built, pkg, gen, w, h, base_qp, n_pic, sr):
+@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,amp", [("mixed", 136, 72, 27, 3, 8, 0), ("textured", 128, 64, 35, 3, 16, 0),
+                                                           ("shear_textured", 192, 128, 27, 3, 16, 1)])      # amp: asymmetric partitions in the coded CTUs
+def test_p_ctus_through_the_adapter_into_the_reference_coder(built, pkg, gen, w, h, base_qp, n_pic, sr, amp):
     prev = None
-    n_inter = 0
+    n_inter = n_amp = 0
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, 5, poc)
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
-        o = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr)
+        o = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, lambda_override=lam, search_range=sr, amp=amp)
         if poc:
-            R = st.RefSearch(w, h, qp, f, search_range=sr)
+            R = st.RefSearch(w, h, qp, f, search_range=sr, amp=amp)
             R.setup_p(prev, lam)
             L = R.L
             L.ref_cabac_frac.restype = C.c_ulonglong
@@ -79,10 +80,12 @@ def test_p_ctus_through_the_adapter_into_the_reference_coder(built, pkg, gen, w,
             got = R.from_hm(stt[:n])
             assert L.ref_cabac_frac() == frac, (poc, a, "Q15 bit counter")
             assert np.array_equal(got[st.O_SORTED], ctx[st.O_SORTED]), (poc, a, "context states")
-            n_inter += int((o.ctu_arrays(a)["pred_mode"] == 0).sum())
+            A = o.ctu_arrays(a)
+            n_inter += int((A["pred_mode"] == 0).sum())
+            n_amp += int(((A["pred_mode"] == 0) & (A["part_size"] >= 4) & (A["part_size"] <= 7)).sum())
         o.deblock()
         prev = [p.copy() for p in o.rec]
-    assert n_inter > 0
+    assert n_inter > 0 and (n_amp > 0) == bool(amp)
 
 
 def test_plane_converters_and_islice_cost(built, pkg):

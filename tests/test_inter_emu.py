@@ -37,19 +37,27 @@ def _fast(case):
     return m.FAST_SEARCH.get(case, 0)
 
 
+def _amp(case):
+    spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.AMP.get(case, 0)
+
+
 def dbk_emu(out_arr, rec, w, h, beta=0, tc=0):
     lib = C.CDLL(os.path.join(ROOT, "tests", "emu", "libdbk_emu.so"))
     lib.dbk_emu.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
     lib.dbk_emu(C.addressof(out_arr), rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, w, h, beta, tc)
 
 
-@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32", "tmvp_mixed_qp30", "tmvp_textured_qp35"])
+@pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32", "tmvp_mixed_qp30", "tmvp_textured_qp35",
+                                  "amp_textured_qp27", "amp_mixed_qp30", "amp_shear_qp27"])
 def test_emulated_engine_p_pictures(case, built, pkg):
     gen, w, h, base_qp, seed, n_pic, sr = _cases()[case]
     g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
     prev = None
     prev_ctus = None
-    n_inter = n_skip = 0
+    n_inter = n_skip = n_amp = 0
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
@@ -57,8 +65,8 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             o, e = hmo_py.Encoder(*f, qp, lambda_override=lam), emu_py.EmuEncoder(*f, qp, lam=lam)
         else:
             col = prev_ctus if _tmvp(case) else None
-            o = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=_fast(case))
-            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case), col=col)
+            o = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=_fast(case), amp=_amp(case))
+            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case), col=col, amp=_amp(case))
         for a in range(o.n_ctu):
             o.compress_ctu(a)
             e.compress_ctu(a)
@@ -69,6 +77,7 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             assert fa == fb and np.array_equal(ca[st.O_SORTED], cb[st.O_SORTED]), (poc, a, "CABAC state")
             n_inter += int((A["pred_mode"] == 0).sum())
             n_skip += int(A["skip"].sum())
+            n_amp += int(((A["part_size"] >= 4) & (A["part_size"] <= 7) & (A["pred_mode"] == 0)).sum()) if _amp(case) else 0
         for p, q in zip(o.rec, e.rec):
             assert np.array_equal(p, q), (poc, "reconstruction")
         prev_ctus = bytes(e.out)                                 # the engine's own array is the next picture's motion field (TMVP)
@@ -81,3 +90,6 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             assert np.array_equal(p, q), (poc, "deblocked picture vs oracle")
         prev = [a.copy() for a in e.rec]
     assert n_inter > 0 and n_skip > 0
+    if case == "amp_shear_qp27":
+        print("partitions of asymmetric CUs:", n_amp)
+        assert n_amp > 0                                         # asymmetric partitions survive into the decided pictures
