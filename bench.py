@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--fast-search", type=int, default=1, help="lowdelay_P integer motion search: 1 = TZ search (FastSearch 1, the reference cfg's setting), 0 = full search")
+    ap.add_argument("--amp", type=int, default=0, help="lowdelay_P: 1 = asymmetric motion partitions (AMP 1 of the reference cfg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep and the transfer measurement")
     ap.add_argument("--shard", choices=["frames", "slices"], default="frames")
@@ -202,6 +203,7 @@ def main():
         fp1 = pkg.engine.ldp_slice(32, 1)
         fp1.search_range = args.search_range
         fp1.fast_search = args.fast_search
+        fp1.amp = args.amp
 
     def bind(ci):
         seed, qp, k = chain_list[ci]
@@ -278,7 +280,7 @@ def main():
         traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
                 f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
-                f"one reference picture, TMVP off, AMP off" if ldp else
+                f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}" if ldp else
                 f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO (BASELINE configs[2])")
         res = {
             "metric": "CTUs/sec (RDO decision only) at 4K " + ("lowdelay_P" if ldp else "all-intra"), "value": value, "unit": "CTUs/sec",
@@ -310,7 +312,7 @@ def main():
                 if ldp:
                     _, q1, lam = hmo_py.ldp_slice(1, 32)
                     mk = lambda fr=fr: hmo_py.Encoder(*fr, q1, slice_ctus=sl if n_sl > 1 else 0, ref=[p.cpu().numpy() for p in _unpad(refs[seeds[0]], W, H)],
-                                                      lambda_override=lam, search_range=args.search_range, fast_search=args.fast_search)
+                                                      lambda_override=lam, search_range=args.search_range, fast_search=args.fast_search, amp=args.amp)
                 else:
                     mk = lambda fr=fr, qp=qp: hmo_py.Encoder(*fr, qp, slice_ctus=sl if n_sl > 1 else 0)
                 look = lambda a, ci=ci: eng.ctu_out(ci, a) if a < walked and switches is None else None
