@@ -38,7 +38,8 @@ struct FcuState {
   int width = 0, height = 0, n_ctu = 0;
   uint8_t *d_org[3] = { nullptr, nullptr, nullptr }, *d_rec[3] = { nullptr, nullptr, nullptr }, *d_ref[3] = { nullptr, nullptr, nullptr };
   uint8_t *d_refsrc[3] = { nullptr, nullptr, nullptr };
-  fcu_ctu_out *d_out = nullptr;
+  fcu_ctu_out *d_out = nullptr;                                /* decisions of the picture being coded ...                          */
+  fcu_ctu_out *d_out_prev = nullptr; Int poc_prev = -1 << 30;  /* ... and of the picture coded before it: the TMVP motion field     */
   std::vector<uint8_t> h_plane[3];
   Int poc_loaded = -1 << 30;
   fcu_ctu_out h_out;
@@ -67,6 +68,7 @@ void ensure_context(const TComSPS *sps)
     S.h_plane[c].resize(plane_bytes(w, h, c));
   }
   HIPOK(hipMalloc((void **)&S.d_out, sizeof(fcu_ctu_out) * (size_t)S.n_ctu));
+  HIPOK(hipMalloc((void **)&S.d_out_prev, sizeof(fcu_ctu_out) * (size_t)S.n_ctu));
 }
 
 void upload(TComPicYuv *pic, uint8_t *const d[3])
@@ -84,8 +86,9 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
   FcuState &S = g_fcu;
   TComPic *pic = pCtu->getPic(); TComSlice *slice = pCtu->getSlice();
   ensure_context(slice->getSPS());
-  if (pic->getPOC() != S.poc_loaded) {                          /* once per picture: the source planes */
+  if (pic->getPOC() != S.poc_loaded) {                          /* once per picture: the source planes; the finished picture's decisions stay resident */
     upload(pic->getPicYuvOrg(), S.d_org);
+    std::swap(S.d_out, S.d_out_prev); S.poc_prev = S.poc_loaded;
     S.poc_loaded = pic->getPOC();
   }
   fcu_frame_params fp;
@@ -105,7 +108,7 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     fp.search_range = cfg->getSearchRange(); fp.fast_enc = cfg->getUseFastEnc(); fp.hadamard_me = cfg->getUseHADME();
     fp.fast_merge_decision = cfg->getUseFastDecisionForMerge(); fp.max_merge_cand = slice->getMaxNumMergeCand();
     fp.fast_search = cfg->getFastSearch() ? 1 : 0;
-    if (slice->getEnableTMVPFlag()) { fprintf(stderr, "TEncCuFcu: run HM with TMVPMode 0 (the collocated motion field is not uploaded by this adapter yet)\n"); exit(1); }
+    fp.tmvp = slice->getEnableTMVPFlag() ? 1 : 0;
     fp.amp = slice->getSPS()->getUseAMP() ? 1 : 0;              /* part sizes 4..7 come back with HM's own PartSize values */
   }
   int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
@@ -116,6 +119,20 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     if (rc != FCU_OK) die("fcu_pad_reference", rc);
     rc = fcu_chain_set_reference(S.ctx, 0, S.d_ref[0], S.d_ref[1], S.d_ref[2]);
     if (rc != FCU_OK) die("fcu_chain_set_reference", rc);
+    if (fp.tmvp) {
+      /* collocated picture = list 0, collocated_ref_idx: with one reference picture that is the picture coded before this
+       * one, whose fcu_ctu_out array is still in HBM.  The engine applies no vector scaling: both POC distances (picture ->
+       * reference, collocated picture -> its reference) must be equal, as they are in a one-reference low-delay chain. */
+      TComPic *col = slice->getRefPic(RefPicList(slice->getColFromL0Flag() ? 0 : 1), slice->getColRefIdx());
+      const Int dCur = slice->getPOC() - slice->getRefPOC(REF_PIC_LIST_0, 0);
+      TComSlice *cs = col->getSlice(0);
+      const Bool colInter = !cs->isIntra();
+      if (col->getPOC() != S.poc_prev || (colInter && (cs->getNumRefIdx(REF_PIC_LIST_0) != 1 || col->getPOC() - cs->getRefPOC(REF_PIC_LIST_0, 0) != dCur))) {
+        fprintf(stderr, "TEncCuFcu: TMVP needs the collocated picture to be the previously coded picture at the same POC distance\n"); exit(1);
+      }
+      rc = fcu_chain_set_collocated(S.ctx, 0, S.d_out_prev);
+      if (rc != FCU_OK) die("fcu_chain_set_collocated", rc);
+    }
   }
   if (fp.slice_ctus > 0) { rc = fcu_chain_set_range(S.ctx, 0, first, count); if (rc != FCU_OK) die("fcu_chain_set_range", rc); }
 }
@@ -151,7 +168,7 @@ Void TEncCu::destroy()
 {
   FcuState &S = g_fcu;
   for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_ref[c]); hipFree(S.d_refsrc[c]); S.d_org[c] = S.d_rec[c] = S.d_ref[c] = S.d_refsrc[c] = nullptr; }
-  hipFree(S.d_out); S.d_out = nullptr;
+  hipFree(S.d_out); hipFree(S.d_out_prev); S.d_out = S.d_out_prev = nullptr; S.poc_prev = -1 << 30;
   if (S.ctx) { fcu_destroy(S.ctx); S.ctx = nullptr; }
   S.width = S.height = 0; S.poc_loaded = -1 << 30;
 }
