@@ -266,6 +266,7 @@ struct alignas(16) Scratch {
   Yuv16 resi_cu, resi_best, qt_resi[4];
   Yuv tmp_pred;
   uint8_t me_pred[9][CTU * CTU];
+  int par_ps[4];                                   /* eParentPartSize of the CU being compressed at each depth (SIZE_NONE: intra / none); read only with AMP on */
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
@@ -300,7 +301,6 @@ struct Shared {
   };
   int dc;
   int best_idx[4], reco_best_idx[4];               /* which of cu[d][0/1] / reco[d][0/1] is "best" */
-  int8_t par_ps[4];                                /* eParentPartSize of the CU being compressed at each depth (SIZE_NONE: intra / none) */
   /* PU / TU mailbox written by serial blocks */
   union {
     struct { int rd_mode[12]; int n_rd; int preds[3]; int n_mpm; };   /* luma PU */
@@ -2765,7 +2765,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       check_rd_cost_inter(D, SIZE_2NxN, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
       if (P.amp && D < MAXDEPTH) {                             /* AMP with AMP_ENC_SPEEDUP + AMP_MRG (:836-943); deriveTestModeAMP (:381-430) */
         const CuObj *bb = cu_best(E, D);
-        const int bps = FCU_UNI((int)bb->part_size[0]), bmrg = FCU_UNI((int)bb->merge_flag[0]), bskip = FCU_UNI((int)bb->skip[0]), par = FCU_UNI((int)g_S.par_ps[D]);
+        const int bps = FCU_UNI((int)bb->part_size[0]), bmrg = FCU_UNI((int)bb->merge_flag[0]), bskip = FCU_UNI((int)bb->skip[0]), par = FCU_UNI(G->par_ps[D]);
         int hor = 0, ver = 0, mhor = 0, mver = 0;
         if (bps == SIZE_2NxN) hor = 1;
         else if (bps == SIZE_Nx2N) ver = 1;
@@ -2808,7 +2808,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
   if constexpr (D < MAXDEPTH) {
    if (!earlyTerminate) {                                    /* bSubBranch = false, TEncCu.cpp:1257-1260 */
     const int nd = D + 1, hs = s >> 1, qn = NPART >> (2 * nd);
-    FCU_SERIAL { const CuObj *b = cu_best(E, D); g_S.par_ps[nd] = (int8_t)((boundary || b->pred_mode[0] != MODE_INTER) ? SIZE_NONE : b->part_size[0]); }   /* eParentPartSize, :1355-1363 */
+    if (P.amp) FCU_SERIAL { const CuObj *b = cu_best(E, D); G->par_ps[nd] = (boundary || b->pred_mode[0] != MODE_INTER) ? SIZE_NONE : b->part_size[0]; }   /* eParentPartSize, :1355-1363 */
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * hs, sy = y + (i >> 1) * hs;
       cu_init(&G->cu[nd][0], nd, sx, sy, zidx + i * qn);
@@ -2931,7 +2931,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
     for (int i = lane; i < 4096; i += 64) out->coeff_y[i] = 0;
     for (int i = lane; i < 1024; i += 64) { out->coeff_cb[i] = 0; out->coeff_cr[i] = 0; }
     cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, 0, CI_CURR_BEST), lane);
-    if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; g_S.par_ps[d] = SIZE_NONE; } out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
+    if (lane == 0) { for (int d = 0; d < 4; d++) { g_S.best_idx[d] = 0; g_S.reco_best_idx[d] = 0; } G->par_ps[0] = SIZE_NONE; out->total_cost = FCU_MAX_DOUBLE; out->total_dist = out->total_bits = out->total_bins = 0; }
   }
   cu_init(&G->cu[0][0], 0, x, y, 0);
   cu_init(&G->cu[0][1], 0, x, y, 0);

@@ -21,20 +21,16 @@
 
 struct Pu { int addr, ox, oy, w, h; };
 FCU_DEV int pu_count(int ps) { return ps == SIZE_2Nx2N ? 1 : (ps == SIZE_NxN ? 4 : 2); }
-FCU_DEV Pu pu_geom(int depth, int ps, int pu)                  /* getPartIndexAndSize / getPartPosition */
+/* getPartIndexAndSize / getPartPosition (TComDataCU.cpp:2165-2240,2706-2772) as a table: per (part size, PU) the offset and size in
+ * quarters of the CU size and the partition address in sixteenths of the CU's partitions (g_auiPUOffset), packed
+ * ox | oy << 4 | w << 8 | h << 12 | addr << 16.  One scalar load instead of a branch ladder per shape. */
+FCU_TABLE uint32_t k_pu_geom[8][4] = { { 0x04400, 0x04400, 0x04400, 0x04400 }, { 0x02400, 0x82420, 0x00000, 0x00000 }, { 0x04200, 0x44202, 0x00000, 0x00000 }, { 0x02200, 0x42202, 0x82220, 0xc2222 }, { 0x01400, 0x23410, 0x00000, 0x00000 }, { 0x03400, 0xa1430, 0x00000, 0x00000 }, { 0x04100, 0x14301, 0x00000, 0x00000 }, { 0x04300, 0x54103, 0x00000, 0x00000 } };
+FCU_DEV Pu pu_geom(int depth, int ps, int pu)
 {
   const int s = CTU >> depth, n = NPART >> (2 * depth);
-  Pu g; g.addr = 0; g.ox = 0; g.oy = 0; g.w = s; g.h = s;
-  if (ps == SIZE_2NxN) { g.h = s >> 1; if (pu) { g.addr = n >> 1; g.oy = s >> 1; } }
-  else if (ps == SIZE_Nx2N) { g.w = s >> 1; if (pu) { g.addr = n >> 2; g.ox = s >> 1; } }
-  else if (ps == SIZE_NxN) { g.w = g.h = s >> 1; g.addr = pu * (n >> 2); g.ox = (pu & 1) * (s >> 1); g.oy = (pu >> 1) * (s >> 1); }
-  else if (ps >= SIZE_2NxnU && ps <= SIZE_nRx2N) {             /* asymmetric: a quarter and three quarters (TComDataCU.cpp:2165-2240) */
-    const int q = s >> 2;
-    if (ps == SIZE_2NxnU) { if (!pu) g.h = q; else { g.h = s - q; g.oy = q; g.addr = n >> 3; } }
-    else if (ps == SIZE_2NxnD) { if (!pu) g.h = s - q; else { g.h = q; g.oy = s - q; g.addr = (n >> 1) + (n >> 3); } }
-    else if (ps == SIZE_nLx2N) { if (!pu) g.w = q; else { g.w = s - q; g.ox = q; g.addr = n >> 4; } }
-    else { if (!pu) g.w = s - q; else { g.w = q; g.ox = s - q; g.addr = (n >> 2) + (n >> 4); } }
-  }
+  const uint32_t e = k_pu_geom[ps][pu];
+  Pu g; g.ox = (int)((e & 7) * s) >> 2; g.oy = (int)(((e >> 4) & 7) * s) >> 2; g.w = (int)(((e >> 8) & 7) * s) >> 2; g.h = (int)(((e >> 12) & 7) * s) >> 2;
+  g.addr = (int)(((e >> 16) & 15) * n) >> 4;
   return g;
 }
 /* does partition i (relative to the CU, n partitions) belong to prediction unit pu?  (TComCUMvField::setAll / setSubPart) */

@@ -111,7 +111,7 @@ def test_full_4k_frame_as_slice_chains(pkg):
     eng.destroy()
 
 
-@pytest.mark.parametrize("qp", [22, 37])
+@pytest.mark.parametrize("qp", [22, 27, 37])
 def test_4k_slices_at_other_qps(pkg, qp):
     """The first six CTU rows of the 4K frame as six slice chains at the other ends of the QP range."""
     w, h, sl, rows = 3840, 2160, 60, 6
