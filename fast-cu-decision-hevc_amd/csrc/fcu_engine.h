@@ -82,9 +82,20 @@ template <class T> static inline T fcu_emu_uni(T v, int site, int line)
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define FCU_ATOMIC_MAX(p, v) atomicMax((p), (v))
-/* wave reductions: cross-lane butterfly (ds_swizzle / DPP through __shfl_xor), then ONE lane touches LDS -- the
- * SAD / SSE / Hadamard partial sums of the inter path (north star: "wavefront __shfl reductions for per-PU costs") */
-__device__ inline uint32_t fcu_wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o); return v; }
+/* wave reductions in registers, then ONE lane touches LDS -- the SAD / SSE / Hadamard partial sums (north star: "wavefront
+ * reductions for per-PU costs").  The sum runs on the DPP path of the VALU (six v_add_u32_dpp: two quad permutes, two row
+ * rotations, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lane 63 then holds the total) instead of
+ * six ds_bpermute round trips through the LDS crossbar (__shfl_xor).  All 64 lanes must be active. */
+__device__ inline uint32_t fcu_wave_sum(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);    /* quad_perm:[1,0,3,2] */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);    /* quad_perm:[2,3,0,1] */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   /* row_ror:4 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   /* row_ror:8: every lane of a row holds the row's sum */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1, 3 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ inline unsigned long long fcu_wave_min64(unsigned long long v)
 {
   for (int o = 32; o > 0; o >>= 1) {
@@ -1671,7 +1682,7 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
       pred[y * bs + x] = (uint8_t)r; recqt[y * bs + x] = (uint8_t)r; recpic[y * rs + x] = (uint8_t)r;
       const int e = org[y * bs + x] - r; sse += (uint32_t)(e * e);
     }
-    FCU_ATOMIC_ADD(&g_S.sad[35], sse);
+    FCU_WAVE_ADD(&g_S.sad[35], sse);
   }
   FCU_SERIAL { const uint32_t sse = g_S.sad[35]; g_S.t_dist = comp ? (uint32_t)(P.chroma_weight * (double)sse) : sse; }
   FCU_TOC(E, t11_, 11);
@@ -2715,7 +2726,7 @@ FCU_DEV FCU_NOINLINE int cu_num_obf(int x, int y, int s)
   FCU_FOR_LANES {
     const int q = s >> 2; int n = 0;
     for (int i = lane; i < q * q; i += 64) n += E.C->obf[((y >> 2) + i / q) * E.C->obf_stride + (x >> 2) + i % q] > 0;
-    if (n) FCU_ATOMIC_ADD(&g_S.dec_cnt, n);
+    FCU_WAVE_ADD((uint32_t *)&g_S.dec_cnt, (uint32_t)n);
   }
   return FCU_UNI(g_S.dec_cnt);
 }
