@@ -138,7 +138,11 @@ template <class T> __device__ inline T fcu_uni(T v)
 /* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
 #if defined(FCU_PROFILE) && !defined(FCU_EMU)
 #define FCU_TIC(v) const long long v = clock64()
-#ifdef FCU_PROFILE_RDOQ   /* slots 11..15 belong to the sub-timers inside the serial RDOQ in this variant */
+#ifdef FCU_PROFILE_INTER  /* P-path variant: slots 0..9 and 11..14 belong to the sections of compress_cu's P branch / pred_inter_search (FCU_ITOC); 10 stays the CTU total */
+#define FCU_ITOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#define FCU_TOC(E_, v, idx) do { if ((idx) == 10 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#define FCU_COUNT(E_, idx, n) do { } while (0)
+#elif defined(FCU_PROFILE_RDOQ)   /* slots 11..15 belong to the sub-timers inside the serial RDOQ in this variant */
 #define FCU_TOC(E_, v, idx) do { if ((idx) < 11 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
 #else
@@ -149,6 +153,9 @@ template <class T> __device__ inline T fcu_uni(T v)
 #define FCU_TIC(v) do { } while (0)
 #define FCU_TOC(E_, v, idx) do { } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
+#endif
+#ifndef FCU_ITOC
+#define FCU_ITOC(E_, v, idx) do { } while (0)
 #endif
 
 #include "fcu_tables.h"
@@ -2683,7 +2690,7 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_inter(int d, int partSize, int useMrg)
   const int n = cu->nparts;
   FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->part_size[i] = (int8_t)partSize; cu->pred_mode[i] = MODE_INTER; } }
   pred_inter_search(cu, partSize, useMrg);
-  encode_res_and_calc_rd_inter_cu(cu, 0);
+  { FCU_TIC(p_); encode_res_and_calc_rd_inter_cu(cu, 0); FCU_ITOC(E, p_, 9); }
   check_best_mode(d);
 }
 /* xCheckRDCostMerge2Nx2N, TEncCu.cpp:1900-2018 (early skip detection off) */
@@ -2707,8 +2714,8 @@ FCU_DEV FCU_NOINLINE void check_rd_cost_merge_2nx2n(int d)
         for (int i = lane; i < n; i += 64) { cu->pred_mode[i] = MODE_INTER; cu->part_size[i] = SIZE_2Nx2N; }
         pu_set_motion(cu, SIZE_2Nx2N, 0, lane, cmv[c][0], cmv[c][1], cref[c]); pu_set_info(cu, SIZE_2Nx2N, 0, lane, 1, c, 0, 0, -1);
       }
-      mc_pu(cu, SIZE_2Nx2N, 0, &G->predt[d], 0);
-      encode_res_and_calc_rd_inter_cu(cu, noRes);
+      { FCU_TIC(p_); mc_pu(cu, SIZE_2Nx2N, 0, &G->predt[d], 0); FCU_ITOC(E, p_, 8); }
+      { FCU_TIC(p_); encode_res_and_calc_rd_inter_cu(cu, noRes); FCU_ITOC(E, p_, noRes ? 12 : 11); }
       FCU_SERIAL { if (noRes == 0 && !qt_root_cbf(cu, 0)) g_S.mrg_buf[c] = 1; }
       check_best_mode(d);
       cu_init(cu_temp(E, d), d, x, y, zidx);
@@ -2769,11 +2776,11 @@ FCU_DEV FCU_NOINLINE void compress_cu()
     cu_init(cu_temp(E, D), D, x, y, zidx);
     int tryIntra = 1;
     if (P.slice_type == SLICE_P) {                           /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
-      check_rd_cost_merge_2nx2n(D);
+      { FCU_TIC(p_); check_rd_cost_merge_2nx2n(D); FCU_ITOC(E, p_, 0); }
       cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_2Nx2N, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_Nx2N, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
-      check_rd_cost_inter(D, SIZE_2NxN, 0); cu_init(cu_temp(E, D), D, x, y, zidx);
+      { FCU_TIC(p_); check_rd_cost_inter(D, SIZE_2Nx2N, 0); FCU_ITOC(E, p_, 1); } cu_init(cu_temp(E, D), D, x, y, zidx);
+      { FCU_TIC(p_); check_rd_cost_inter(D, SIZE_Nx2N, 0); FCU_ITOC(E, p_, 2); } cu_init(cu_temp(E, D), D, x, y, zidx);
+      { FCU_TIC(p_); check_rd_cost_inter(D, SIZE_2NxN, 0); FCU_ITOC(E, p_, 3); } cu_init(cu_temp(E, D), D, x, y, zidx);
       if (P.amp && D < MAXDEPTH) {                             /* AMP with AMP_ENC_SPEEDUP + AMP_MRG (:836-943); deriveTestModeAMP (:381-430) */
         const CuObj *bb = cu_best(E, D);
         const int bps = FCU_UNI((int)bb->part_size[0]), bmrg = FCU_UNI((int)bb->merge_flag[0]), bskip = FCU_UNI((int)bb->skip[0]), par = FCU_UNI(G->par_ps[D]);
@@ -2797,7 +2804,8 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       const CuObj *b = cu_best(E, D);                          /* intra only when the best inter candidate has a residual (:1033-1036) */
       tryIntra = FCU_UNI((int)(b->cbf[0][0] | b->cbf[1][0] | b->cbf[2][0])) != 0;
     }
-    if (!skip2Nx2N && tryIntra) check_rd_cost_intra(D, SIZE_2Nx2N);      /* :1040; skipped => the best cost stays MAX_DOUBLE (:1077) */
+    { FCU_TIC(p_); if (!skip2Nx2N && tryIntra) check_rd_cost_intra(D, SIZE_2Nx2N);      /* :1040; skipped => the best cost stays MAX_DOUBLE (:1077) */
+      FCU_ITOC(E, p_, 4); }
     cu_init(cu_temp(E, D), D, x, y, zidx);
     if (D == MAXDEPTH && !earlyTerminate && tryIntra) {      /* :1141-1143 */
       FCU_SERIAL { g_S.dec_j0 = cu_best(E, D)->cost; g_S.dec_flip = g_S.best_idx[D]; }

@@ -548,9 +548,9 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
     if (!normalMC) {                                         /* the cleared motion field (:3356-3363) */
       FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, 0, 0, -1); pu_set_info(cu, ps, pu, lane, 0, 0, 0, 0, -1); }
     } else {
-    int mvpIdx = estimate_mvp(cu, ps, pu);
+    FCU_TIC(p5_); int mvpIdx = estimate_mvp(cu, ps, pu); FCU_ITOC(E, p5_, 5);
     int predx = FCU_UNI(g_S.amvp[mvpIdx][0]), predy = FCU_UNI(g_S.amvp[mvpIdx][1]);
-    motion_estimation(cu, ps, pu, predx, predy, mbBits + 1);
+    { FCU_TIC(p_); motion_estimation(cu, ps, pu, predx, predy, mbBits + 1); FCU_ITOC(E, p_, 6); }
     mvx = FCU_UNI(g_S.me_out[0]); mvy = FCU_UNI(g_S.me_out[1]);
     bitsT = FCU_UNI(g_S.acc[12]); uint32_t costT = FCU_UNI(g_S.acc[13]);
     {                                                        /* xCheckBestMVP */
@@ -570,6 +570,7 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
     }
     FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); pu_set_info(cu, ps, pu, lane, 0, 0, mvx - predx, mvy - predy, mvpIdx); }
     }
+    FCU_TIC(p7_);
     if (ps != SIZE_2Nx2N) {                                  /* merge estimation of the PU (TEncSearch.cpp:3448-3498) */
       const uint32_t meCost = normalMC ? inter_pred_error(cu, ps, pu) + motion_cost(P, bitsT) : 0xffffffffu;
       FCU_SERIAL merge_candidates(cu, ps, pu);
@@ -590,7 +591,8 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
         FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); const int n = cu->nparts; for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) { cu->merge_flag[i] = 0; cu->merge_idx[i] = 0; cu->inter_dir[i] = 1; } }
       }
     }
-    mc_pu(cu, ps, pu, &G->predt[d], 0);
+    FCU_ITOC(E, p7_, 7);
+    { FCU_TIC(p_); mc_pu(cu, ps, pu, &G->predt[d], 0); FCU_ITOC(E, p_, 8); }
   }
 }
 

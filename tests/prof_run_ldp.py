@@ -1,0 +1,34 @@
+"""Section profile of the P path (diagnostic build -DFCU_PROFILE -DFCU_PROFILE_INTER as libfcu_prof_inter.so): a measurement
+script, not a test.  Decides picture 0 (intra) and picture 1 (P) of `clips` 4K clips and prints the share of the P picture's
+CTU time spent in the sections of compress_cu's P branch."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import __graft_entry__ as g
+
+pkg = g.load_package()
+pkg.engine._lib = None
+pkg.engine.lib_path = lambda: os.path.join(os.path.dirname(pkg.engine.__file__), os.environ.get("FCU_LIB", "libfcu_prof_inter.so"))
+import torch
+from bench import gen_moving_gpu
+
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+amp = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+W, H = 3840, 2160
+dev = torch.device("cuda", 0)
+dec = pkg.lowdelay.LowDelayPDecider(W, H, 32, n_clips=clips, search_range=64, slice_ctus=120, fast_search=1, amp=bool(amp))
+for poc in range(2):
+    frames = [gen_moving_gpu(torch, dev, W, H, seed=7 + c, poc=poc) for c in range(clips)]
+    dec.decide_picture(frames)
+names = ["merge_2Nx2N", "inter_2Nx2N", "inter_Nx2N", "inter_2NxN", "intra_2Nx2N", "estimate_mvp", "motion_estimation", "pu_merge_est", "mc_pu",
+         "inter_encode_res", "ctu_total", "merge_res_coded", "merge_res_skip"]
+acc = np.zeros(17)
+n = clips * 17
+for c in range(0, n, max(1, n // 64)):
+    acc += np.array(dec.eng.debug_counters(c), dtype=float)
+tot = acc[10]
+for i, nm in enumerate(names):
+    print("%-18s %6.2f%%" % (nm, 100 * acc[i] / tot))
