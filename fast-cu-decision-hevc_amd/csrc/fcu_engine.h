@@ -193,6 +193,7 @@ enum { CTX_SPLIT = 0, CTX_PARTSIZE = 3, CTX_INTRA_LUMA = 4, CTX_CHROMA_PRED = 5,
        CTX_SKIP = 160, CTX_MERGE_FLAG = 163, CTX_MERGE_IDX = 164, CTX_PRED_MODE = 165, CTX_PARTSIZE1 = 166, CTX_MVD = 169,
        CTX_REF = 171, CTX_MVP_IDX = 173, CTX_ROOT_CBF = 174, NCTX = 176 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
+enum { MEMO_K = 6, MEMO_POOL = 6144 + 1536 + 384 + 96 };    /* slots per depth; levels (or residual samples) of one slot of every depth: 1.5 * (64 >> d)^2 */
 enum { MAXVC = 20, MAXLC = 16, POOL = 5120 };   /* MAXVC candidate variants of a batch, MAXLC lane-private coders (the bit count runs in rounds) */
 /* <= 8 RMD survivors + 2 MPMs (iMode, TEncSearch.cpp:2407-2428), x2 transform-skip variants; 5 x 32x32 */
 #define FCU_MAX_DOUBLE 1.7e+308
@@ -285,6 +286,15 @@ struct alignas(16) Scratch {
   Yuv tmp_pred;
   uint8_t me_pred[9][CTU * CTU];
   int par_ps[4];                                   /* eParentPartSize of the CU being compressed at each depth (SIZE_NONE: intra / none); read only with AMP on */
+  /* Residual-coding memo of the inter candidates of ONE CU (encode_res_and_calc_rd_inter_cu): the inter RQT is a function of
+   * the CU's prediction (= its per-partition motion field), the source block and the coder snapshot [depth][CI_CURR_BEST],
+   * none of which change between the candidates of a CU except the motion.  Candidates whose motion field equals an earlier
+   * one's (merge candidates with equal vectors, Nx2N / 2NxN / AMP shapes that found the 2Nx2N vector twice) reuse its transform
+   * tree, levels and residual instead of searching them again.  Slots are per depth, FIFO, cleared when a CU starts. */
+  int memo_valid[4][MEMO_K], memo_next[4], memo_zero[4][MEMO_K];
+  int16_t memo_mv[4][MEMO_K][NPART][2]; int8_t memo_ref[4][MEMO_K][NPART];
+  uint8_t memo_tr_idx[4][MEMO_K][NPART], memo_cbf[4][MEMO_K][3][NPART], memo_tskip[4][MEMO_K][3][NPART];
+  alignas(16) int16_t memo_coef[MEMO_K * MEMO_POOL], memo_resi[MEMO_K * MEMO_POOL];
 };
 
 struct Env { Chain *C; Scratch *G; int cur_ctu, slice_start; };
@@ -2775,7 +2785,8 @@ FCU_DEV FCU_NOINLINE void compress_cu()
     }
     cu_init(cu_temp(E, D), D, x, y, zidx);
     int tryIntra = 1;
-    if (P.slice_type == SLICE_P) {                           /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
+    if (P.slice_type == SLICE_P) {                           /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM off) */
+      FCU_FOR_LANES { if (lane < MEMO_K) G->memo_valid[D][lane] = 0; if (lane == MEMO_K) G->memo_next[D] = 0; }
       { FCU_TIC(p_); check_rd_cost_merge_2nx2n(D); FCU_ITOC(E, p_, 0); }
       cu_init(cu_temp(E, D), D, x, y, zidx);
       { FCU_TIC(p_); check_rd_cost_inter(D, SIZE_2Nx2N, 0); FCU_ITOC(E, p_, 1); } cu_init(cu_temp(E, D), D, x, y, zidx);

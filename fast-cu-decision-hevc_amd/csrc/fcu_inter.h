@@ -1007,6 +1007,34 @@ FCU_DEV FCU_NOINLINE void encode_res_and_calc_rd_inter_cu(CuObj *cu, int skipRes
     FCU_FOR_LANES cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane);
     return;
   }
+  /* memo lookup (Scratch::memo_*): a slot of this depth whose motion field equals this candidate's */
+  const int memoBase = d == 0 ? 0 : (d == 1 ? 6144 : (d == 2 ? 6144 + 1536 : 6144 + 1536 + 384)), ySz = s * s, cSz = hs * hs;
+  int hit = -1;
+  for (int k = 0; k < MEMO_K && hit < 0; k++) {
+    if (!FCU_UNI(G->memo_valid[d][k])) continue;
+    FCU_SERIAL g_S.uni[5] = 0;
+    FCU_FOR_LANES {
+      int bad = 0;
+      for (int i = lane; i < n; i += 64) bad |= (G->memo_mv[d][k][i][0] != cu->mv[i][0]) | (G->memo_mv[d][k][i][1] != cu->mv[i][1]) | (G->memo_ref[d][k][i] != cu->ref_idx[i]);
+      if (bad) g_S.uni[5] = 1;
+    }
+    if (!FCU_UNI(g_S.uni[5])) hit = k;
+  }
+  int zeroOut;
+  if (hit >= 0) {
+    zeroOut = FCU_UNI(G->memo_zero[d][hit]);
+    const int16_t *mc = G->memo_coef + hit * MEMO_POOL + memoBase, *mr = G->memo_resi + hit * MEMO_POOL + memoBase;
+    FCU_FOR_LANES {
+      for (int i = lane; i < n; i += 64) { cu->tr_idx[i] = G->memo_tr_idx[d][hit][i]; for (int c = 0; c < 3; c++) { cu->cbf[c][i] = G->memo_cbf[d][hit][c][i]; cu->tskip[c][i] = G->memo_tskip[d][hit][c][i]; } }
+      if (!zeroOut) {
+        for (int i = lane; i < ySz; i += 64) { cu->coef[0][i] = mc[i]; G->resi_best.y[(i / s) * 64 + i % s] = mr[i]; }
+        for (int i = lane; i < cSz; i += 64) {
+          cu->coef[1][i] = mc[ySz + i]; cu->coef[2][i] = mc[ySz + cSz + i];
+          const int o = (i / hs) * 32 + i % hs; G->resi_best.u[o] = mr[ySz + i]; G->resi_best.v[o] = mr[ySz + cSz + i];
+        }
+      }
+    }
+  } else {
   FCU_FOR_LANES {                                            /* residual of the CU */
     for (int i = lane; i < s * s; i += 64) { const int o = (i / s) * 64 + i % s; G->resi_cu.y[o] = (int16_t)(org->y[o] - pred->y[o]); }
     for (int i = lane; i < hs * hs; i += 64) { const int o = (i / hs) * 32 + i % hs; G->resi_cu.u[o] = (int16_t)(org->u[o] - pred->u[o]); G->resi_cu.v[o] = (int16_t)(org->v[o] - pred->v[o]); }
@@ -1020,15 +1048,34 @@ FCU_DEV FCU_NOINLINE void encode_res_and_calc_rd_inter_cu(CuObj *cu, int skipRes
     const double zeroCost = rd_cost(P, cab_bits(CAB_GOON), g_S.iq_zero);
     g_S.uni[4] = (zeroCost < g_S.iq_cost[0] || !qt_root_cbf(cu, 0)) ? 1 : 0;
   }
-  const int zeroOut = FCU_UNI(g_S.uni[4]);
+  zeroOut = FCU_UNI(g_S.uni[4]);
   if (zeroOut) { FCU_FOR_LANES { for (int i = lane; i < n; i += 64) { cu->tr_idx[i] = 0; for (int c = 0; c < 3; c++) { cu->cbf[c][i] = 0; cu->tskip[c][i] = 0; } } } }
   else set_inter_residual_qt_data(cu, 0);
+  }
   FCU_FOR_LANES {
     cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
     if (cu->merge_flag[0] && cu->part_size[0] == SIZE_2Nx2N && zeroOut) for (int i = lane; i < n; i += 64) cu->skip[i] = 1;   /* xAddSymbolBitsInter */
   }
   FCU_SERIAL { cab_reset_bits(CAB_GOON); encode_cu_syntax_inter(E, CAB_GOON, cu, 0, d); cu->bits = cab_bits(CAB_GOON); }
-  if (!zeroOut) set_inter_residual_qt_data(cu, 1);
+  if (!zeroOut && hit < 0) set_inter_residual_qt_data(cu, 1);
+  if (hit < 0) {                                             /* memo store: next slot of this depth */
+    const int k = FCU_UNI(G->memo_next[d]);
+    int16_t *mc = G->memo_coef + k * MEMO_POOL + memoBase, *mr = G->memo_resi + k * MEMO_POOL + memoBase;
+    FCU_FOR_LANES {
+      for (int i = lane; i < n; i += 64) {
+        G->memo_mv[d][k][i][0] = cu->mv[i][0]; G->memo_mv[d][k][i][1] = cu->mv[i][1]; G->memo_ref[d][k][i] = cu->ref_idx[i];
+        G->memo_tr_idx[d][k][i] = cu->tr_idx[i]; for (int c = 0; c < 3; c++) { G->memo_cbf[d][k][c][i] = cu->cbf[c][i]; G->memo_tskip[d][k][c][i] = cu->tskip[c][i]; }
+      }
+      if (!zeroOut) {
+        for (int i = lane; i < ySz; i += 64) { mc[i] = cu->coef[0][i]; mr[i] = G->resi_best.y[(i / s) * 64 + i % s]; }
+        for (int i = lane; i < cSz; i += 64) {
+          mc[ySz + i] = cu->coef[1][i]; mc[ySz + cSz + i] = cu->coef[2][i];
+          const int o = (i / hs) * 32 + i % hs; mr[ySz + i] = G->resi_best.u[o]; mr[ySz + cSz + i] = G->resi_best.v[o];
+        }
+      }
+      if (lane == 0) { G->memo_zero[d][k] = zeroOut; G->memo_valid[d][k] = 1; G->memo_next[d] = k + 1 == MEMO_K ? 0 : k + 1; }
+    }
+  }
   FCU_FOR_LANES { cab_copy(slot_ptr(E, d, CI_TEMP_BEST), &g_S.cab[CAB_GOON], lane); if (lane < 3) g_S.acc[lane] = 0; }
   FCU_FOR_LANES {                                            /* reconstruction + final distortion */
     uint32_t e0 = 0, e1 = 0, e2 = 0;
