@@ -285,6 +285,7 @@ struct alignas(16) Scratch {
   Yuv16 resi_cu, resi_best, qt_resi[4];
   Yuv tmp_pred;
   uint8_t me_pred[9][CTU * CTU];
+  int16_t me_h[3][72 * 64];                        /* sub-sample refinement: the three horizontally filtered planes of a round (14-bit intermediates, xExtDIFUpSamplingH/Q) */
   int par_ps[4];                                   /* eParentPartSize of the CU being compressed at each depth (SIZE_NONE: intra / none); read only with AMP on */
   /* Residual-coding memo of the inter candidates of ONE CU (encode_res_and_calc_rd_inter_cu): the inter RQT is a function of
    * the CU's prediction (= its per-partition motion field), the source block and the coder snapshot [depth][CI_CURR_BEST],

@@ -477,6 +477,7 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   ltx >>= 2; lty >>= 2; rbx >>= 2; rby >>= 2;
   const int nx = rbx - ltx + 1, ny = rby - lty + 1, step = (P.fast_enc && g.h > 8) ? 2 : 1;
   int bx, by;
+  FCU_TIC(pi_);
   if (P.fast_search) {                                       /* xPatternSearchFast -> xTZSearch; m_integerMv2Nx2N, TEncSearch.cpp:3822-3833 */
     TzCtx t; t.org = org; t.ref0 = ref0; t.rs = rs; t.px = px; t.py = py; t.w = g.w; t.h = g.h; t.step = step; t.predx = predx; t.predy = predy;
     const int usePred = ps != SIZE_2Nx2N || cu->depth_cu != 0;
@@ -500,16 +501,43 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   const unsigned bp = (unsigned)FCU_UNI((int)(unsigned)(g_S.me_best & 0xffffffffull));
   bx = ltx + (int)(bp % (unsigned)nx); by = lty + (int)(bp / (unsigned)nx);
   }
+  FCU_ITOC(E, pi_, 13);                                        /* profile: integer search | sub-sample refinement */
+  FCU_TIC(pf_);
   /* half-sample round, then quarter-sample round around the winner */
   int hx = 0, hy = 0, qx = 0, qy = 0; uint32_t bestD = 0;
   for (int round = 0; round < 2; round++) {
     const int basex = (bx << 2) + 2 * hx, basey = (by << 2) + 2 * hy, stp = round == 0 ? 2 : 1;
-    FCU_FOR_LANES {                                          /* the nine interpolated blocks */
+    /* The nine interpolated blocks, separably (as xExtDIFUpSamplingH / Q build them, TEncSearch.cpp:5431-5560): the round has
+     * three horizontal positions, so three horizontally filtered planes (unshifted 8-tap sums, <= 15 bits) over the rows any
+     * of its vertical positions touches, then nine vertical 8-tap passes.  Same integers as the two-dimensional sum
+     * clip8((sum_v sum_h c_v c_h s + 2048) >> 12) that interp_sample evaluates, at 16 instead of 64 multiplies per sample. */
+    const int iyMin = (basey - stp) >> 2, iyMax = (basey + stp) >> 2, rows = g.h + 7 + (iyMax - iyMin);
+    FCU_FOR_LANES {
       if (lane < 9) g_S.acc[lane] = 0;
+      for (int k = lane; k < 3 * rows * g.w; k += 64) {
+        const int pl = k / (rows * g.w), r = k - pl * rows * g.w, yy = r / g.w, x = r - yy * g.w;
+        const int mvx = basex + (pl - 1) * stp, fx = mvx & 3;
+        const uint8_t *p = ref0 + (py + iyMin - 3 + yy) * rs + px + x + (mvx >> 2);
+        int s;
+        if (!fx) s = 64 * p[0];
+        else { s = 0;
+#pragma unroll
+          for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * p[t - 3]; }
+        G->me_h[pl][yy * 64 + x] = (int16_t)s;
+      }
+    }
+    FCU_FOR_LANES {
       for (int k = lane; k < 9 * g.w * g.h; k += 64) {
         const int c = k / (g.w * g.h), r = k - c * g.w * g.h, y = r / g.w, x = r - y * g.w;
         const int8_t *t = round == 0 ? k_refine_h[c] : k_refine_q[c];
-        G->me_pred[c][y * 64 + x] = (uint8_t)interp_sample(ref0, rs, 0, px + x, py + y, basex + stp * t[0], basey + stp * t[1]);
+        const int mvy = basey + stp * t[1], fy = mvy & 3;
+        const int16_t *q = G->me_h[t[0] + 1] + (y + (mvy >> 2) - iyMin) * 64 + x;      /* row of tap j: y + iy + (j - 3), stored from iyMin - 3 */
+        int s;
+        if (!fy) s = 64 * q[3 * 64];
+        else { s = 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) s += k_luma_filter[fy][j] * q[j * 64]; }
+        G->me_pred[c][y * 64 + x] = (uint8_t)clip8((s + 2048) >> 12);
       }
     }
     for (int c = 0; c < 9; c++) {
@@ -532,6 +560,7 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   const int mvx = (bx << 2) + 2 * hx + qx, mvy = (by << 2) + 2 * hy + qy;
   const uint32_t mvBits = mv_bits(mvx, mvy, predx, predy, 0), bits = bitsIn + mvBits;
   const uint32_t cost = (uint32_t)(FCU_FLOOR(1.0 * ((double)bestD - (double)motion_cost(P, mvBits))) + (double)motion_cost(P, bits));
+  FCU_ITOC(E, pf_, 14);
   FCU_SERIAL { g_S.me_out[0] = mvx; g_S.me_out[1] = mvy; g_S.acc[12] = bits; g_S.acc[13] = cost; }
 }
 
@@ -572,14 +601,28 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
     }
     FCU_TIC(p7_);
     if (ps != SIZE_2Nx2N) {                                  /* merge estimation of the PU (TEncSearch.cpp:3448-3498) */
-      const uint32_t meCost = normalMC ? inter_pred_error(cu, ps, pu) + motion_cost(P, bitsT) : 0xffffffffu;
+      /* the prediction error of the PU is a function of its vector: candidates that repeat the motion search's result or an
+       * earlier candidate's vector (the usual case under coherent motion) reuse the error instead of predicting again */
+      int seenX[6], seenY[6], seenR[6], nSeen = 0; uint32_t seenE[6];
+      uint32_t meCost = 0xffffffffu;
+      if (normalMC) { const uint32_t e = inter_pred_error(cu, ps, pu); meCost = e + motion_cost(P, bitsT); seenX[0] = mvx; seenY[0] = mvy; seenR[0] = 0; seenE[0] = e; nSeen = 1; }
       FCU_SERIAL merge_candidates(cu, ps, pu);
       uint32_t mrgCost = 0xffffffffu; int mrgIdx = 0;
       const int nc = P.max_merge_cand;
       for (int c = 0; c < nc; c++) {                          /* xMergeEstimation */
         const int cx = FCU_UNI(g_S.mrg_mv[c][0]), cy = FCU_UNI(g_S.mrg_mv[c][1]), cr = FCU_UNI(g_S.mrg_ref[c]);
-        FCU_FOR_LANES pu_set_motion(cu, ps, pu, lane, cx, cy, cr);
-        uint32_t cc = inter_pred_error(cu, ps, pu);
+        int found = -1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < nSeen && seenX[k] == cx && seenY[k] == cy && seenR[k] == cr) found = k;
+        uint32_t cc;
+        if (found >= 0) cc = seenE[found];
+        else {
+          FCU_FOR_LANES pu_set_motion(cu, ps, pu, lane, cx, cy, cr);
+          cc = inter_pred_error(cu, ps, pu);
+#pragma unroll
+          for (int k = 0; k < 6; k++) if (k == nSeen) { seenX[k] = cx; seenY[k] = cy; seenR[k] = cr; seenE[k] = cc; }
+          nSeen++;
+        }
         uint32_t b = (uint32_t)c + 1; if (c == nc - 1) b--;
         cc += motion_cost(P, b);
         if (cc < mrgCost) { mrgCost = cc; mrgIdx = c; }

@@ -24,7 +24,7 @@ for poc in range(2):
     frames = [gen_moving_gpu(torch, dev, W, H, seed=7 + c, poc=poc) for c in range(clips)]
     dec.decide_picture(frames)
 names = ["merge_2Nx2N", "inter_2Nx2N", "inter_Nx2N", "inter_2NxN", "intra_2Nx2N", "estimate_mvp", "motion_estimation", "pu_merge_est", "mc_pu",
-         "inter_encode_res", "ctu_total", "merge_res_coded", "merge_res_skip"]
+         "inter_encode_res", "ctu_total", "merge_res_coded", "merge_res_skip", "me_integer", "me_fractional"]
 acc = np.zeros(17)
 n = clips * 17
 for c in range(0, n, max(1, n // 64)):
