@@ -540,7 +540,16 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
         G->me_pred[c][y * 64 + x] = (uint8_t)clip8((s + 2048) >> 12);
       }
     }
-    for (int c = 0; c < 9; c++) {
+    if (P.had_me) {                                          /* Hadamard units of all nine blocks share the lanes: 9 x units items, one per lane */
+      FCU_FOR_LANES {
+        const int u8 = !(g.w & 7) && !(g.h & 7), us = u8 ? 8 : 4, bw = g.w / us, nb = bw * (g.h / us);
+        for (int it = lane; it < 9 * nb; it += 64) {
+          const int c = it / nb, u = it - c * nb, uy = u / bw, ux = u - uy * bw, o = uy * us * 64 + ux * us;
+          const uint32_t s = u8 ? had_unit<8>(org + o, 64, G->me_pred[c] + o, 64) : had_unit<4>(org + o, 64, G->me_pred[c] + o, 64);
+          FCU_ATOMIC_ADD(&g_S.acc[c], s);
+        }
+      }
+    } else for (int c = 0; c < 9; c++) {
       FCU_FOR_LANES {
         if (P.had_me) had_block_lanes(lane, org, 64, G->me_pred[c], 64, g.w, g.h, &g_S.acc[c]);
         else { uint32_t s = 0; for (int i = lane; i < g.w * g.h; i += 64) s += (uint32_t)iabs(org[(i / g.w) * 64 + i % g.w] - G->me_pred[c][(i / g.w) * 64 + i % g.w]); FCU_WAVE_ADD(&g_S.acc[c], s); }
