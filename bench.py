@@ -69,11 +69,20 @@ def gen_textured_gpu(torch, dev, w, h, seed, shift=(0, 0)):
     return f(Y), f(U), f(V)
 
 
-def gen_moving_gpu(torch, dev, w, h, seed, poc):
+def gen_moving_gpu(torch, dev, w, h, seed, poc, shear=0, vec=(3, 1)):
     """picture `poc` of a lowdelay_P clip: one smooth-noise texture (seeded per clip) moving by (3, 1) samples per picture
-    plus fresh +-2 noise -- the same recipe as tests/search_trace.py:moving_frame, on the device"""
+    plus fresh +-2 noise -- the same recipe as tests/search_trace.py:moving_frame, on the device.  shear: bands of the
+    picture (rows 48..63 of every 64 in the left half, columns 0..15 of every 64 in the right half) show a second texture
+    moving by (-2, 3): motion boundaries inside the CUs, so the partition shapes of a CU find different vectors."""
+    if shear:
+        a = gen_moving_gpu(torch, dev, w, h, seed, poc)
+        b = gen_moving_gpu(torch, dev, w, h, seed + 50000, poc, vec=(-2, 3))
+        yy = torch.arange(h, device=dev)[:, None]; xx = torch.arange(w, device=dev)[None, :]
+        m = torch.where(xx < w // 2, (yy % 64) >= 48, (xx % 64) < 16)
+        mc = m[::2, ::2]
+        return torch.where(m, b[0], a[0]).contiguous(), torch.where(mc, b[1], a[1]).contiguous(), torch.where(mc, b[2], a[2]).contiguous()
     Y, U, V = gen_textured_gpu(torch, dev, w + 32, h + 32, seed)
-    dx, dy = (3 * poc) % 32, poc % 32
+    dx, dy = (vec[0] * poc) % 32, (vec[1] * poc) % 32
     g = torch.Generator(device=dev)
     g.manual_seed(100000 + 17 * seed + poc)
     n = torch.randint(-2, 3, (h, w), generator=g, device=dev, dtype=torch.int16)
@@ -121,6 +130,7 @@ def main():
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--fast-search", type=int, default=1, help="lowdelay_P integer motion search: 1 = TZ search (FastSearch 1, the reference cfg's setting), 0 = full search")
     ap.add_argument("--amp", type=int, default=0, help="lowdelay_P: 1 = asymmetric motion partitions (AMP 1 of the reference cfg)")
+    ap.add_argument("--shear", type=int, default=0, help="lowdelay_P: 1 = clips with motion boundaries inside the CUs (bands moving with a second vector) instead of one global motion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep and the transfer measurement")
     ap.add_argument("--shard", choices=["frames", "slices"], default="frames")
@@ -178,7 +188,7 @@ def main():
 
     frames, recs, outs, refs, fps = {}, {}, {}, {}, {}
     for seed in seeds:
-        frames[seed] = gen_moving_gpu(torch, dev, W, H, seed, 1 if ldp else 0) if ldp else gen_textured_gpu(torch, dev, W, H, seed)
+        frames[seed] = gen_moving_gpu(torch, dev, W, H, seed, 1 if ldp else 0, shear=args.shear) if ldp else gen_textured_gpu(torch, dev, W, H, seed)
     for seed in seeds:
         for qp in qps:
             recs[(seed, qp)] = [torch.zeros_like(p) for p in frames[seed]]
@@ -187,7 +197,7 @@ def main():
     if ldp:
         # untimed: picture 0 of every clip (intra, same slice structure), loop filter, padding -> the reference pictures
         fp0 = pkg.engine.ldp_slice(32, 0)
-        pic0 = {seed: gen_moving_gpu(torch, dev, W, H, seed, 0) for seed in seeds}
+        pic0 = {seed: gen_moving_gpu(torch, dev, W, H, seed, 0, shear=args.shear) for seed in seeds}
         for ci, (seed, qp, k) in enumerate(chain_list):
             eng.init_chain(ci, pic0[seed], fp0.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp0)
             if n_sl > 1:
@@ -280,7 +290,7 @@ def main():
         traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
                 f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
-                f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}" if ldp else
+                f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}{'; sheared motion (--shear 1)' if args.shear else ''}" if ldp else
                 f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO (BASELINE configs[2])")
         res = {
             "metric": "CTUs/sec (RDO decision only) at 4K " + ("lowdelay_P" if ldp else "all-intra"), "value": value, "unit": "CTUs/sec",
