@@ -17,11 +17,12 @@ from bench import gen_moving_gpu
 
 clips = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 amp = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+shear = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 W, H = 3840, 2160
 dev = torch.device("cuda", 0)
 dec = pkg.lowdelay.LowDelayPDecider(W, H, 32, n_clips=clips, search_range=64, slice_ctus=120, fast_search=1, amp=bool(amp))
 for poc in range(2):
-    frames = [gen_moving_gpu(torch, dev, W, H, seed=7 + c, poc=poc) for c in range(clips)]
+    frames = [gen_moving_gpu(torch, dev, W, H, seed=7 + c, poc=poc, shear=shear) for c in range(clips)]
     dec.decide_picture(frames)
 names = ["merge_2Nx2N", "inter_2Nx2N", "inter_Nx2N", "inter_2NxN", "intra_2Nx2N", "estimate_mvp", "motion_estimation", "pu_merge_est", "mc_pu",
          "inter_encode_res", "ctu_total", "merge_res_coded", "merge_res_skip", "me_integer", "me_fractional"]
