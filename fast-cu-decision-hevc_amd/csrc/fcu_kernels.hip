@@ -104,6 +104,20 @@ const char *fcu_last_error(void) { return g_err; }
 #endif
 #define FCU_STR2(x) #x
 #define FCU_STR(x) FCU_STR2(x)
+int fcu_abi_sizeof(int which)
+{
+  switch (which) {
+  case FCU_ABI_CTU_OUT: return (int)sizeof(fcu_ctu_out);
+  case FCU_ABI_SEQ_PARAMS: return (int)sizeof(fcu_seq_params);
+  case FCU_ABI_FRAME_PARAMS: return (int)sizeof(fcu_frame_params);
+  case FCU_ABI_DECISION_PARAMS: return (int)sizeof(fcu_decision_params);
+  case FCU_ABI_VERIFY_COUNTS: return (int)sizeof(fcu_verify_counts);
+  case FCU_ABI_SAO_CTU: return (int)sizeof(fcu_sao_ctu);
+  case FCU_ABI_SAO_PARAMS: return (int)sizeof(fcu_sao_params);
+  case FCU_ABI_PU_TRACE: return (int)sizeof(fcu_pu_trace);
+  default: return -1;
+  }
+}
 const char *fcu_build_info(void)
 {
   return "hipcc clang " __clang_version__ " HIP " FCU_STR(HIP_VERSION_MAJOR) "." FCU_STR(HIP_VERSION_MINOR) "." FCU_STR(HIP_VERSION_PATCH)

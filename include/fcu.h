@@ -265,6 +265,11 @@ const char *fcu_last_error(void);
 /* compiler version and the exact flags libfcu.so was built with.  The engine relies on
  * `-mllvm -amdgpu-remove-redundant-endcf=false`: a build without it is refused by tests/test_cabi.py. */
 const char *fcu_build_info(void);
+/* sizeof() of the ABI's structures as this library was compiled, by FCU_ABI_* index (-1 for an unknown index): a binding
+ * in another language (ctypes, cgo, JNI) checks its own layouts against them before the first call; tests/test_cabi.py does. */
+enum { FCU_ABI_CTU_OUT = 0, FCU_ABI_SEQ_PARAMS = 1, FCU_ABI_FRAME_PARAMS = 2, FCU_ABI_DECISION_PARAMS = 3, FCU_ABI_VERIFY_COUNTS = 4,
+       FCU_ABI_SAO_CTU = 5, FCU_ABI_SAO_PARAMS = 6, FCU_ABI_PU_TRACE = 7 };
+int  fcu_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

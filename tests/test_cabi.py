@@ -54,6 +54,22 @@ def test_struct_layouts_match_between_binding_and_oracle(built, pkg):
         assert getattr(pkg.engine.CtuOut, n1).offset == getattr(hmo_py.Ctu, n2).offset
 
 
+def test_binding_layouts_match_the_library(built, pkg):
+    """The ctypes structures of engine.py against sizeof() inside libfcu.so (fcu_abi_sizeof): a field added on one side only
+    (the round-2 `amp` parameter was the occasion) must fail here, not corrupt memory on the GPU box.  Defaults of the frame
+    parameters are checked on the way (host arithmetic, no GPU)."""
+    e = pkg.engine
+    lib = C.CDLL(pkg.lib_path())
+    want = {0: C.sizeof(e.CtuOut), 1: C.sizeof(e.SeqParams), 2: C.sizeof(e.FrameParams), 3: C.sizeof(e.DecisionParams),
+            4: C.sizeof(e.VerifyCounts), 5: C.sizeof(e.SaoCtu), 6: C.sizeof(e.SaoParams), 7: e.PU_TRACE_DTYPE.itemsize}
+    for which, size in want.items():
+        assert lib.fcu_abi_sizeof(which) == size, (which, lib.fcu_abi_sizeof(which), size)
+    assert lib.fcu_abi_sizeof(99) == -1
+    fp = e.FrameParams()
+    lib.fcu_default_frame_params(C.byref(fp), 32)
+    assert (fp.qp, fp.rdoq, fp.rdoq_ts, fp.amp, fp.tmvp, fp.fast_search, fp.max_merge_cand, fp.search_range) == (32, 1, 1, 0, 0, 0, 5, 64)
+
+
 def test_no_gpu_means_loud_failure(built, pkg):
     import torch
     if torch.cuda.is_available():
