@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames", type=int, default=0, help="frames (intra) / clips (ldp) per GPU; 0 = 120 (intra: x4 QPs x17 slices = 8160 chains) / 240 (ldp: x17 slices = 4080 chains)")
     ap.add_argument("--slice-ctus", type=int, default=120, help="HM SliceMode 1 / SliceArgument: CTUs per slice = per chain (0: one slice per frame)")
-    ap.add_argument("--ctus-per-step", type=int, default=0, help="0 = walk the whole slice over warmup + steps launches (intra) / 2 (ldp)")
+    ap.add_argument("--ctus-per-step", type=int, default=0, help="0 = walk the whole slice over warmup + steps launches; lowdelay_P with the full search: 2")
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--fast-search", type=int, default=1, help="lowdelay_P integer motion search: 1 = TZ search (FastSearch 1, the reference cfg's setting), 0 = full search")
@@ -169,7 +169,9 @@ def main():
     n_sl = (n_ctu + sl - 1) // sl
     qps = [32] if ldp else [int(q) for q in args.qps.split(",")]
     n_frames = args.frames or (240 if ldp else 120)
-    cps = args.ctus_per_step or (2 if ldp else max(1, sl // (args.warmup + args.steps)))
+    # whole slices are walked over warmup + steps launches (interior CTUs, second CTU row, partial bottom row in the timed
+    # region); only the full search of lowdelay_P, 5x slower, keeps to 2 CTUs per step
+    cps = args.ctus_per_step or (2 if (ldp and not args.fast_search) else max(1, sl // (args.warmup + args.steps)))
     walked = (args.warmup + args.steps) * cps
     assert walked <= sl, "bench walks past the end of the slice"
     strong = args.shard == "slices" and world > 1
