@@ -35,7 +35,7 @@ ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 102
 # two chroma blocks with their interpolation margin 2 x (32 + 8)^2 -- SURVEY.md 8(d) gives no figure for configs[4]; DESIGN.md 3e
 algo_bytes_ldp = lambda sr: ALGO_BYTES_PER_CTU + (64 + 2 * sr) ** 2 + 2 * (32 + 8) ** 2
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = {"intra": os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "ldp": os.path.join(ROOT, "profiles", "r02_pmc_summary_ldp.json")}
 
 
 def measured_traffic(config, chains, ctus_per_step):
@@ -43,7 +43,7 @@ def measured_traffic(config, chains, ctus_per_step):
     (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and the
     commit the profiled library was built from.  None when the summary is for another workload shape."""
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(PMC_SUMMARY[config]) as f:
             d = json.load(f)
         if d.get("config") != config or d.get("chains_per_launch") != chains or d.get("ctus_per_chain_per_launch") != ctus_per_step:
             return None, None
