@@ -311,7 +311,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profile_commit": prof_commit,
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_ctu": algo,
-                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about 1.8 TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3"},
+                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about %s TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3" % ("3.1" if ldp else "1.8")},
         }
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if world == 1 and not args.no_cpu_baseline:
