@@ -526,18 +526,27 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
         G->me_h[pl][yy * 64 + x] = (int16_t)s;
       }
     }
+    /* vertical passes: a lane owns one column of one block and slides an eight-row window of the horizontal plane down it
+     * in registers -- one load per output sample instead of eight (the kernel waits on memory three quarters of the time) */
     FCU_FOR_LANES {
-      for (int k = lane; k < 9 * g.w * g.h; k += 64) {
-        const int c = k / (g.w * g.h), r = k - c * g.w * g.h, y = r / g.w, x = r - y * g.w;
+      for (int it = lane; it < 9 * g.w; it += 64) {
+        const int c = it / g.w, x = it - c * g.w;
         const int8_t *t = round == 0 ? k_refine_h[c] : k_refine_q[c];
         const int mvy = basey + stp * t[1], fy = mvy & 3;
-        const int16_t *q = G->me_h[t[0] + 1] + (y + (mvy >> 2) - iyMin) * 64 + x;      /* row of tap j: y + iy + (j - 3), stored from iyMin - 3 */
-        int s;
-        if (!fy) s = 64 * q[3 * 64];
-        else { s = 0;
-#pragma unroll
-          for (int j = 0; j < 8; j++) s += k_luma_filter[fy][j] * q[j * 64]; }
-        G->me_pred[c][y * 64 + x] = (uint8_t)clip8((s + 2048) >> 12);
+        const int16_t *q = G->me_h[t[0] + 1] + ((mvy >> 2) - iyMin) * 64 + x;           /* row of tap j of output row y: y + j (stored from iyMin - 3) */
+        uint8_t *o = G->me_pred[c] + x;
+        if (!fy) { for (int y = 0; y < g.h; y++) o[y * 64] = (uint8_t)clip8((64 * q[(y + 3) * 64] + 2048) >> 12); }
+        else {
+          const int f0 = k_luma_filter[fy][0], f1 = k_luma_filter[fy][1], f2 = k_luma_filter[fy][2], f3 = k_luma_filter[fy][3],
+                    f4 = k_luma_filter[fy][4], f5 = k_luma_filter[fy][5], f6 = k_luma_filter[fy][6], f7 = k_luma_filter[fy][7];
+          int w0 = q[0], w1 = q[64], w2 = q[128], w3 = q[192], w4 = q[256], w5 = q[320], w6 = q[384];
+          for (int y = 0; y < g.h; y++) {
+            const int w7 = q[(y + 7) * 64];
+            const int s = f0 * w0 + f1 * w1 + f2 * w2 + f3 * w3 + f4 * w4 + f5 * w5 + f6 * w6 + f7 * w7;
+            o[y * 64] = (uint8_t)clip8((s + 2048) >> 12);
+            w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
+          }
+        }
       }
     }
     if (P.had_me) {                                          /* Hadamard units of all nine blocks share the lanes: 9 x units items, one per lane */
