@@ -251,9 +251,10 @@ FCU_DEV uint32_t had_unit(const uint8_t *org, int so, const uint8_t *pred, int s
 #pragma unroll
   for (int i = 0; i < USZ * USZ; i++) acc[i] = 0;
   for (int y = 0; y < USZ; y++) {
-    int row[USZ];
+    int row[USZ]; uint8_t o[USZ], p[USZ];
+    __builtin_memcpy(o, org + y * so, USZ); __builtin_memcpy(p, pred + y * sp, USZ);      /* one 8- / 4-byte load per row and operand */
 #pragma unroll
-    for (int x = 0; x < USZ; x++) row[x] = (int)org[y * so + x] - (int)pred[y * sp + x];
+    for (int x = 0; x < USZ; x++) row[x] = (int)o[x] - (int)p[x];
 #pragma unroll
     for (int len = 1; len < USZ; len <<= 1)
 #pragma unroll
