@@ -178,18 +178,18 @@ FCU_DEV int interp_sample(const uint8_t *ref, int rs, int comp, int x, int y, in
   const uint8_t *p = ref + (y + (mvy >> sh)) * rs + x + (mvx >> sh);
   if (!fx && !fy) return p[0];
   if (comp == 0) {
-    if (!fy) { int s = 0;
+    if (!fy) { int s = 0; uint8_t b[8]; __builtin_memcpy(b, p - 3, 8);
 #pragma unroll
-      for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * p[t - 3];
+      for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * b[t];
       return clip8((s + 32) >> 6); }
     if (!fx) { int s = 0;
 #pragma unroll
       for (int t = 0; t < 8; t++) s += k_luma_filter[fy][t] * p[(t - 3) * rs];
       return clip8((s + 32) >> 6); }
     int s = 0;
-    for (int j = 0; j < 8; j++) { int h = 0; const uint8_t *q = p + (j - 3) * rs;
+    for (int j = 0; j < 8; j++) { int h = 0; uint8_t b[8]; __builtin_memcpy(b, p + (j - 3) * rs - 3, 8);
 #pragma unroll
-      for (int t = 0; t < 8; t++) h += k_luma_filter[fx][t] * q[t - 3];
+      for (int t = 0; t < 8; t++) h += k_luma_filter[fx][t] * b[t];
       s += k_luma_filter[fy][j] * h; }
     return clip8((s + 2048) >> 12);
   }
@@ -239,7 +239,8 @@ FCU_DEV uint32_t sad_block(const uint8_t *org, const uint8_t *r, int rs, int w, 
   uint32_t s = 0;
   for (int y = 0; y < h; y += step) {
     const uint8_t *o = org + y * 64, *q = r + y * rs;
-    for (int x = 0; x < w; x += 4) { uint32_t a, b; __builtin_memcpy(&a, o + x, 4); __builtin_memcpy(&b, q + x, 4); s = fcu_sad_u8(a, b, s); }
+    if (!(w & 7)) for (int x = 0; x < w; x += 8) { uint32_t a[2], b[2]; __builtin_memcpy(a, o + x, 8); __builtin_memcpy(b, q + x, 8); s = fcu_sad_u8(a[0], b[0], s); s = fcu_sad_u8(a[1], b[1], s); }
+    else for (int x = 0; x < w; x += 4) { uint32_t a, b; __builtin_memcpy(&a, o + x, 4); __builtin_memcpy(&b, q + x, 4); s = fcu_sad_u8(a, b, s); }
   }
   return s;
 }
@@ -521,9 +522,9 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
         const uint8_t *p = ref0 + (py + iyMin - 3 + yy) * rs + px + x + (mvx >> 2);
         int s;
         if (!fx) s = 64 * p[0];
-        else { s = 0;
+        else { uint8_t b[8]; __builtin_memcpy(b, p - 3, 8); s = 0;                    /* the eight taps' samples in one load */
 #pragma unroll
-          for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * p[t - 3]; }
+          for (int t = 0; t < 8; t++) s += k_luma_filter[fx][t] * b[t]; }
         G->me_h[pl][yy * 64 + x] = (int16_t)s;
       }
     }
