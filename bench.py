@@ -289,7 +289,7 @@ def main():
         per_launch = timed_ctus_gpu / max(1, args.steps)
         algo = algo_bytes_ldp(args.search_range) if ldp else ALGO_BYTES_PER_CTU
         achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if switches is None else (None, None)
+        traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if (switches is None and not args.amp and not args.shear) else (None, None)
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
                 f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
                 f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}{'; sheared motion (--shear 1)' if args.shear else ''}" if ldp else
@@ -311,7 +311,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profile_commit": prof_commit,
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_ctu": algo,
-                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about %s TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3" % ("3.1" if ldp else "1.8")},
+                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about %s TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3" % ("2.9" if ldp else "1.8")},
         }
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if world == 1 and not args.no_cpu_baseline:
