@@ -93,3 +93,47 @@ def test_emulated_engine_p_pictures(case, built, pkg):
     if case == "amp_shear_qp27":
         print("partitions of asymmetric CUs:", n_amp)
         assert n_amp > 0                                         # asymmetric partitions survive into the decided pictures
+
+
+def test_random_small_clips_on_the_emulator(built, pkg):
+    """A CPU-side slice of tests/parity_sweep_ldp.py: random small lowdelay clips (global or sheared motion, QP, search range,
+    TZ / full search, TMVP, AMP, slices) through the engine source on the wave emulator against the oracle, every field of
+    every CTU.  Fixed seed: the cases are the same in every run."""
+    rng = np.random.default_rng(8081)
+    for case in range(16):
+        w, h = int(rng.integers(8, 21)) * 8, int(rng.integers(8, 17)) * 8
+        base_qp = int(rng.integers(18, 42))
+        gen = ["smooth", "mixed", "textured"][int(rng.integers(0, 3))]
+        if rng.random() < 0.5:
+            gen = "shear_" + gen
+        sr = int(rng.choice([4, 8, 16]))
+        fast, tmvp, amp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+        sl = int(rng.choice([0, 1, n_ctu]))
+        seed = int(rng.integers(0, 1000))
+        prev = prev_ctus = None
+        for poc in range(2):
+            f = st.moving_frame(pkg.synth, gen, w, h, seed, poc, shift=(int(rng.integers(-4, 5)), int(rng.integers(-2, 3))) if poc else (0, 0))
+            _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+            if not 0 <= qp <= 51:
+                break
+            if poc == 0:
+                o, e = hmo_py.Encoder(*f, qp, slice_ctus=sl, lambda_override=lam), emu_py.EmuEncoder(*f, qp, slice_ctus=sl, lam=lam)
+            else:
+                col = prev_ctus if tmvp else None
+                o = hmo_py.Encoder(*f, qp, slice_ctus=sl, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
+                e = emu_py.EmuEncoder(*f, qp, slice_ctus=sl, ref=prev, lam=lam, search_range=sr, fast_search=fast, col=col, amp=amp)
+            for a in range(o.n_ctu):
+                o.compress_ctu(a)
+                e.compress_ctu(a)
+                A, B = o.ctu_arrays(a), e.ctu_arrays(a)
+                for k, v in A.items():
+                    assert (np.array_equal(v, B[k]) if isinstance(v, np.ndarray) else v == B[k]), (case, gen, w, h, poc, a, k)
+            for p, q in zip(o.rec, e.rec):
+                assert np.array_equal(p, q), (case, poc, "reconstruction")
+            prev_ctus = bytes(e.out)
+            dbk_emu(e.out, e.rec, w, h)
+            o.deblock()
+            for p, q in zip(o.rec, e.rec):
+                assert np.array_equal(p, q), (case, poc, "deblocked picture")
+            prev = [a.copy() for a in e.rec]
