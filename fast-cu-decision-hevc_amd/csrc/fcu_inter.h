@@ -2,8 +2,10 @@
  * fcu_inter.h -- the P-slice half of the CTU engine (BASELINE configs[4]); included by fcu_engine.h inside namespace fcu.
  *
  * Configuration built: one reference picture (list 0 = the previous picture after the loop filters,
- * padded planes), TMVP off, AMP off, full integer search (FastSearch 0) with FEN sub-sampling, half / quarter refinement
- * on Hadamard cost, FDM, MaxNumMergeCand 5, QuadtreeTUMaxDepthInter 3.  Replaces, per routine (paths in the reference):
+ * padded planes), TMVP and AMP optional (frame parameters), TZ search (FastSearch 1) or full integer search with FEN
+ * sub-sampling, half / quarter refinement on Hadamard cost, FDM, MaxNumMergeCand 5, QuadtreeTUMaxDepthInter 3.  The inter
+ * candidates of a CU that predict the same block share one residual coding (Scratch::memo_*).  Replaces, per routine
+ * (paths in the reference):
  *   TEncCu::xCheckRDCostMerge2Nx2N / xCheckRDCostInter                     TEncCu.cpp:1900-2062
  *   TEncSearch::predInterSearch, xEstimateMvPredAMVP, xMotionEstimation,
  *     xPatternSearch, xPatternSearchFracDIF, xCheckBestMVP, xMergeEstimation TEncSearch.cpp:2905-4375
