@@ -142,7 +142,7 @@ template <class T> __device__ inline T fcu_uni(T v)
 #define FCU_ITOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_TOC(E_, v, idx) do { if ((idx) == 10 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
-#elif defined(FCU_PROFILE_RDOQ)   /* slots 11..15 belong to the sub-timers inside the serial RDOQ in this variant */
+#elif defined(FCU_PROFILE_RDOQ) || defined(FCU_PROFILE_DEPTH)   /* slots 11..15 belong to the sub-timers inside the serial RDOQ (FCU_PROFILE_DEPTH: 11..14 to the time spent at CU depth 0..3 without its sub-CUs) in these variants */
 #define FCU_TOC(E_, v, idx) do { if ((idx) < 11 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
 #else
@@ -2756,10 +2756,20 @@ FCU_DEV void count_verify(Chain *C, int d, int predictSkip, int partitionTrue, d
   else { C->ver[d][partitionTrue ? 3 : 2] += 1.0; if (partitionTrue) C->ver[d][5] += loss; }
 }
 
+/* -DFCU_PROFILE -DFCU_PROFILE_DEPTH: prof[11 + D] = ticks spent at CU depth D without its sub-CUs (what a wave-per-depth
+ * frontier could overlap; measured on MI355X: 13 / 17 / 21 / 48 % for depths 0..3) */
+#if defined(FCU_PROFILE) && defined(FCU_PROFILE_DEPTH) && !defined(FCU_EMU)
+#define FCU_DTIC(v) long long v = clock64()
+#define FCU_DADD(E_, v, idx, sign) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)((sign) * (clock64() - v)); } while (0)
+#else
+#define FCU_DTIC(v) do { } while (0)
+#define FCU_DADD(E_, v, idx, sign) do { } while (0)
+#endif
 template <int D>
 FCU_DEV FCU_NOINLINE void compress_cu()
 {
   const Env E = env_get();
+  FCU_DTIC(dt_);
   Scratch *G = E.G; const Params &P = E.C->p;
   const CuObj *b0 = cu_best(E, D);
   const int x = b0->x, y = b0->y, zidx = b0->zidx, s = CTU >> D;
@@ -2846,7 +2856,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
       cu_init(&G->cu[nd][1], nd, sx, sy, zidx + i * qn);
       if (sx < P.width && sy < P.height) {
         FCU_FOR_LANES cab_copy(slot_ptr(E, nd, CI_CURR_BEST), i == 0 ? slot_ptr(E, D, CI_CURR_BEST) : slot_ptr(E, nd, CI_NEXT_BEST), lane);
-        compress_cu<D + 1>();
+        { FCU_DTIC(dc_); compress_cu<D + 1>(); FCU_DADD(E, dc_, 11 + D, -1); }   /* the child's time is not this depth's */
         cu_copy_part_from(cu_temp(E, D), cu_best(E, nd), i);
         {                                                    /* xCopyYuv2Tmp */
           const Yuv *src = &G->reco[nd][g_S.reco_best_idx[nd]]; Yuv *dst = &G->reco[D][1 - g_S.reco_best_idx[D]];
@@ -2878,6 +2888,7 @@ FCU_DEV FCU_NOINLINE void compress_cu()
   }
   cu_copy_to_pic(cu_best(E, D));
   copy_reco_to_pic(&G->reco[D][g_S.reco_best_idx[D]], x, y, s);
+  FCU_DADD(E, dt_, 11 + D, 1);
 }
 
 /* ---- encodeCtu replay: xEncodeCU, TEncCu.cpp:1679-1778 (serial, iterative) --------------- */

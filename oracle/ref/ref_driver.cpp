@@ -47,6 +47,7 @@
 #include "TLibEncoder/TEncSampleAdaptiveOffset.h"
 #include "TLibEncoder/TEncTop.h"
 #include "TLibEncoder/TEncCu.h"
+#include "TLibEncoder/TEncSlice.h"
 #undef private
 #undef protected
 #include <math.h>
@@ -693,4 +694,23 @@ void ref_adapter_planes_roundtrip(int comp, const unsigned char *in, unsigned ch
   fcu_adapter::narrow_plane(g_pic->getPicYuvRec(), c, out);
 }
 
+/* ---- the fork's pre-pass: TEncSlice::getOutlierWithDCT (TEncSlice.cpp:878-1173), the reference's own member function.
+ * It touches no member of TEncSlice (only its TComPic argument, globals, partialButterfly and TCMprocessOneSequence), so it
+ * runs on zeroed storage of the class's size: constructing a TEncSlice would need TEncTop / TEncGOP, which are not built.
+ * The source plane is g_pic's PicYuvOrg (ref_set_org); out = the OBF count map, (width / 4) x (height / 4). */
+void ref_obf(short *out)
+{
+  TEncSlice *s = (TEncSlice *)calloc(1, sizeof(TEncSlice));
+  s->getOutlierWithDCT(g_pic);
+  free(s);
+  TComPicYuv *o = g_pic->getOBF(); const Pel *p = o->getAddr(COMPONENT_Y); const int st = o->getStride(COMPONENT_Y);
+  const int w = g_sps.getPicWidthInLumaSamples() / 4, h = g_sps.getPicHeightInLumaSamples() / 4;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) out[y * w + x] = p[y * st + x];
+}
+
 } /* extern "C" */
+
+/* the two output streams the reference's main program defines (App/TAppEncoder/encmain.cpp:52-53) and getOutlierWithDCT
+ * writes its picture dumps to: the driver plays main here; they are never opened, so the writes go nowhere */
+ofstream OutlierYuvFile;
+ofstream OBFFile;

@@ -33,7 +33,8 @@ for c in range(0,frames*4,max(1,frames*4//64)):
     packed+=int(dc[15])
     acc+=np.array(dc,dtype=float)
 tot=acc[10]
-for i,n in enumerate(names): print('%-16s %6.2f%%'%(n,100*acc[i]/tot))
+nsamp=len(range(0,frames*4,max(1,frames*4//64)))*nct
+for i,n in enumerate(names): print('%-16s %6.2f%%  %8.2f Mticks/CTU'%(n,100*acc[i]/tot,acc[i]/nsamp/1e6))
 n=len(range(0,frames*4,max(1,frames*4//64)))*nct
 print('seq rdoq calls/CTU', (packed>>40)/n, 'active coefficient iterations/CTU', (packed & ((1<<40)-1))/n)
 print('tu trials/CTU', acc[16]/ (len(range(0,frames*4,max(1,frames*4//64)))*nct))

@@ -1,7 +1,7 @@
-"""Fork pre-pass (outlier-block-flag map, TEncSlice::getOutlierWithDCT): the threshold fit against golden vectors from the
-REFERENCE'S OWN TCMprocessOneSequence (tests/golden/tcm.npz, oracle/ref/make_golden_tcm.py: TEncSlice.cpp:193-392 compiled
-in place), oracle self-consistency on CPU, the HIP kernels against the oracle on the GPU.  The 4x4 DCT underneath is the
-leaf-pinned one; the loop that feeds the fit (getOutlierWithDCT itself, a TEncSlice member) stays restated by reading."""
+"""Fork pre-pass (outlier-block-flag map, TEncSlice::getOutlierWithDCT): the whole pre-pass against the OBF maps the
+REFERENCE'S OWN getOutlierWithDCT produced (tests/golden/obf.npz, oracle/ref/make_golden_obf.py: TEncSlice.cpp:878-1173
+compiled in place and run through oracle/ref/ref_driver.cpp:ref_obf) -- oracle on the CPU, the HIP kernels on the GPU --,
+the threshold fit alone against the reference's TCMprocessOneSequence (tests/golden/tcm.npz), oracle self-consistency."""
 import ctypes as C
 import os
 
@@ -78,6 +78,35 @@ def test_tcm_fit_matches_the_reference(built, pkg):
         ye = le.fcu_tcm_threshold(hu.ctypes.data, hu.size, n)
         assert ye == g["yc"][i], (i, peak, n, ye, g["yc"][i])
     assert n_def >= 20
+
+
+OBF_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obf.npz")
+
+
+def _obf_cases(pkg):
+    g = np.load(OBF_GOLD)
+    for i, (gen, (w, h), seed) in enumerate(zip(g["gen"], g["size"], g["seed"])):
+        yield str(gen), int(w), int(h), getattr(pkg.synth, str(gen))(int(w), int(h), seed=int(seed))[0], g["obf%d" % i]
+
+
+def test_oracle_prepass_matches_the_reference(pkg):
+    """hmo_obf.c == the reference's getOutlierWithDCT on every fixture picture (sizes on and off the 16-sample grid)."""
+    n = 0
+    for gen, w, h, Y, want in _obf_cases(pkg):
+        obf, _ = hmo_py.obf_prepass(Y)
+        assert np.array_equal(obf, want), (gen, w, h, int((obf != want).sum()))
+        n += 1
+    assert n >= 6
+
+
+@pytest.mark.gpu
+def test_gpu_prepass_matches_the_reference(pkg):
+    """fcu_obf_prepass (obf_hist -> host fit -> obf_count) == the reference's own OBF maps."""
+    for gen, w, h, Y, want in _obf_cases(pkg):
+        eng = pkg.CuEngine(w, h, max_chains=1)
+        obf, yc, ms = eng.obf_prepass(Y[None])
+        assert np.array_equal(obf.cpu().numpy()[0], want), (gen, w, h)
+        eng.destroy()
 
 
 @pytest.mark.gpu
