@@ -113,7 +113,10 @@ struct HmoEnc {
   HmoPuTrace *pu_trace;         /* optional per-PU record of the luma search (hmo_set_pu_trace) */
 };
 /* trace events: candidate about to be searched / searched (its results sit in temp[depth], reco_temp[depth], slot[depth][CI_TEMP_BEST]) */
-enum { HMO_EV_INTRA_BEGIN = 0, HMO_EV_INTRA_END = 1, HMO_EV_INTER_BEGIN = 2, HMO_EV_INTER_END = 3, HMO_EV_MERGE_BEGIN = 4, HMO_EV_MERGE_END = 5 };
+enum { HMO_EV_INTRA_BEGIN = 0, HMO_EV_INTRA_END = 1, HMO_EV_INTER_BEGIN = 2, HMO_EV_INTER_END = 3, HMO_EV_MERGE_BEGIN = 4, HMO_EV_MERGE_END = 5,
+       /* a CU that lies inside the picture: before its first candidate (arg = eParentPartSize) / after its last one, before the
+        * split flag is priced: best[depth], reco_best[depth] and slot[depth][CI_NEXT_BEST] hold the surviving candidate */
+       HMO_EV_CU_BEGIN = 6, HMO_EV_CU_DONE = 7 };
 
 /* ---- hmo_cabac.c */
 static inline void hmo_cabac_copy(HmoCabac *d, const HmoCabac *s) { *d = *s; }

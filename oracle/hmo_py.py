@@ -61,7 +61,7 @@ class Yuv(C.Structure):
 SIZE_2Nx2N, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN = 0, 1, 2, 3
 SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N = 4, 5, 6, 7
 CI_CURR_BEST, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT = range(6)
-EV_INTRA_BEGIN, EV_INTRA_END, EV_INTER_BEGIN, EV_INTER_END, EV_MERGE_BEGIN, EV_MERGE_END = range(6)
+EV_INTRA_BEGIN, EV_INTRA_END, EV_INTER_BEGIN, EV_INTER_END, EV_MERGE_BEGIN, EV_MERGE_END, EV_CU_BEGIN, EV_CU_DONE = range(8)
 TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)
 
 
@@ -181,9 +181,10 @@ class Encoder:
         return (a if full else a[:160]), int(c.frac)
 
     # -- test hooks (hmo_int.h: trace)
-    def set_trace(self, fn):
-        """fn(event, depth, arg) around every CU candidate (EV_* above)"""
-        self._trace = TRACE_FN(lambda user, ev, d, a: fn(ev, d, a))
+    def set_trace(self, fn, cu_events=False):
+        """fn(event, depth, arg) around every CU candidate (EV_* above); cu_events: also EV_CU_BEGIN / EV_CU_DONE around
+        the candidates of every CU (arg = eParentPartSize)"""
+        self._trace = TRACE_FN(lambda user, ev, d, a: fn(ev, d, a) if (cu_events or ev < EV_CU_BEGIN) else None)
         self.lib.hmo_set_trace(self.h, self._trace, None)
 
     def test_cu(self, depth, best=False):

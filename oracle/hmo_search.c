@@ -856,6 +856,7 @@ static void compress_cu(HmoEnc *e, int d, int parentPartSize)
     }
     cu_init(e->temp[d], d, x, y, zidx);
     int tryIntra = 1;
+    if (e->trace) e->trace(e->trace_user, HMO_EV_CU_BEGIN, d, parentPartSize);
     if (e->p.slice_type == HMO_SLICE_P) {                       /* inter candidates first (TEncCu.cpp:753-943; ESD / CFM / AMP off) */
       check_rd_cost_merge_2nx2n(e, d);                          /* :774 */
       cu_init(e->temp[d], d, x, y, zidx);
@@ -889,6 +890,7 @@ static void compress_cu(HmoEnc *e, int d, int parentPartSize)
       j1 = partitionTrue ? e->best[d]->cost : e->temp[d]->cost; /* :1175-1183 */
       cu_init(e->temp[d], d, x, y, zidx);
     }
+    if (e->trace) e->trace(e->trace_user, HMO_EV_CU_DONE, d, parentPartSize);
     if (e->best[d]->cost != HMO_MAX_DOUBLE) {               /* fork: TEncCu.cpp:1224 */
       hmo_reset_bits(e);
       code_split_flag(e, e->best[d], 0, d);

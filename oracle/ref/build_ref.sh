@@ -50,6 +50,16 @@ if [ ! -f "$o" ] || [ "$s" -nt "$o" ]; then
   sed -E '/^#include "TLibCommon\/(linear|tools_YS)\.h"/d' "$s" | g++ $FLAGS -include <(fix) -include limits -x c++ -c - -o "$o" & pids="$pids $!"
 fi
 objs="$objs $o"
+# TEncCu.cpp without the body of xCompressCU (lines 456-1616: its fork code calls into tools_YS.cpp / OpenCV and is not behind a
+# switch), without the fork's two #includes and two extern model pointers (:48-49, :56-57), without xCheckRDCostIntra_Rough
+# (:78-156, dead with SKIP_RDO_ENABLE 0) and without the g_iQP bookkeeping line (:1650).  What remains is the reference's own
+# xCheckRDCostMerge2Nx2N, xCheckRDCostInter, xCheckRDCostIntra, xCheckBestMode, deriveTestModeAMP, xCopyYuv2Pic/Tmp ...
+# The class is renamed in flight (-DTEncCu=TEncCuRef): the repository's adapter defines TEncCu's public methods in this library.
+o="$OUT/obj/TEncCuRef.o"; s="$REF/Lib/TLibEncoder/TEncCu.cpp"
+if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ "$0" -nt "$o" ]; then
+  sed -E '48,49d;56,57d;78,156d;456,1616d;1650d' "$s" | g++ $FLAGS -DTEncCu=TEncCuRef -include <(fix) -include limits -x c++ -c - -o "$o" & pids="$pids $!"
+fi
+objs="$objs $o"
 for p in $pids; do wait $p; done
 # the HM adapter of this repository (adapter/TEncCuFcu.cpp: TEncCu's public methods over libfcu.so) is compiled against the
 # same headers and linked in, so that tests can push fcu_ctu_out data through its marshalling into a real TComDataCU and

@@ -48,6 +48,13 @@
 #include "TLibEncoder/TEncTop.h"
 #include "TLibEncoder/TEncCu.h"
 #include "TLibEncoder/TEncSlice.h"
+/* The reference's own TEncCu.cpp is compiled next to the repository's adapter (which defines TEncCu's public methods over
+ * libfcu.so) under the class name TEncCuRef: build_ref.sh passes -DTEncCu=TEncCuRef to that translation unit only, and this
+ * driver sees the same class declaration a second time under that name. */
+#define TEncCu TEncCuRef
+#undef __TENCCU__
+#include "TLibEncoder/TEncCu.h"
+#undef TEncCu
 #undef private
 #undef protected
 #include <math.h>
@@ -450,13 +457,68 @@ static void read_cu(TComDataCU *cu, int depth, RefCuOut *o)
     for (int y = 0; y < w; y++) for (int x = 0; x < w; x++) { o->reco[c][y * w + x] = (unsigned char)r[y * rs + x]; o->pred[c][y * w + x] = (unsigned char)pp[y * ps + x]; }
   }
 }
-/* One intra CU candidate through the reference: the body of TEncCu::xCheckRDCostIntra (TEncCu.cpp:2064-2141) --
- * estIntraPredLumaQT, luma reconstruction to the picture, estIntraPredChromaQT, the CU's syntax on the go-on coder,
- * calcRdCost.  The caller has loaded the picture state the search reads: PicYuvOrg, PicYuvRec (ref_set_org / ref_set_rec),
- * the CTUs' decided arrays (ref_set_ctu_field) and the coder slot [depth][CI_CURR_BEST] (ref_coder_set).
- * `stage`: 1 = luma search only (BASELINE configs[1]), 2 = luma + chroma + CU bits. */
+/* ---- CU level: the reference's own xCheckRDCostMerge2Nx2N / xCheckRDCostInter / xCheckRDCostIntra / xCheckBestMode /
+ * deriveTestModeAMP (TEncCu.cpp:381,1900,2025,2064,2213; compiled from the reference's TEncCu.cpp without the body of
+ * xCompressCU, whose fork code needs OpenCV) on a TEncCuRef object that shares the driver's search / quantiser / RD-cost /
+ * entropy objects and RD coder slots.  ref_cu_run evaluates all candidates of ONE CU from the state the caller loaded
+ * (picture, neighbours, coder slot [depth][CI_CURR_BEST]) in xCompressCU's order (TEncCu.cpp:753-1143 -- that order, the
+ * cbf gate of the intra test and the AMP call pattern are what this function restates; every call is the reference's) and
+ * returns the CU that survived: the best / temp swaps of xCheckBestMode, the TEMP_BEST -> NEXT_BEST coder hand-over and the
+ * FastDecisionForMerge early-outs inside xCheckRDCostMerge2Nx2N are the reference's own. */
+static TEncCuRef *g_cuRef = 0;
+static void cu_ref_setup(void)
+{
+  if (!g_cuRef) { g_cuRef = new TEncCuRef(); g_cuRef->create(4, 64, 64, CHROMA_420); }
+  /* (re)bound on every call: ref_setup / ref_search_setup make new objects for every picture */
+  g_cuRef->m_pcEncCfg = g_cfg; g_cuRef->m_pcPredSearch = g_search; g_cuRef->m_pcTrQuant = g_trq; g_cuRef->m_pcRdCost = g_rd;
+  g_cuRef->m_pcEntropyCoder = g_ent; g_cuRef->m_pcBinCABAC = 0; g_cuRef->m_pppcRDSbacCoder = g_rdSbac; g_cuRef->m_pcRDGoOnSbacCoder = g_goOn;
+  g_cuRef->m_pcRateCtrl = 0;
+}
+/* best / temp CU of `depth` positioned at (ctu, zidx) the way xCompressCU finds them on entry: initCtu, then initSubCU
+ * down the quadtree (TEncCu.cpp:332-334,1337-1339) */
+static void cu_ref_position(int ctu, int zidx, int depth)
+{
+  g_cuRef->m_ppcBestCU[0]->initCtu(g_pic, ctu); g_cuRef->m_ppcTempCU[0]->initCtu(g_pic, ctu);
+  for (int d = 1; d <= depth; d++) {
+    const int part = (zidx >> (2 * (4 - d))) & 3;
+    g_cuRef->m_ppcBestCU[d]->initSubCU(g_cuRef->m_ppcTempCU[d - 1], part, d, g_qp);
+    g_cuRef->m_ppcTempCU[d]->initSubCU(g_cuRef->m_ppcTempCU[d - 1], part, d, g_qp);
+  }
+  g_cuRef->m_ppcOrigYuv[depth]->copyFromPicYuv(g_pic->getPicYuvOrg(), ctu, zidx);       /* TEncCu.cpp:474 */
+}
+static void read_cu_ref(TComDataCU *cu, int depth, TComYuv *reco, TComYuv *pred, RefCuOut *o)
+{
+  TComYuv *r0 = g_yReco[depth], *p0 = g_yPred[depth];
+  g_yReco[depth] = reco; g_yPred[depth] = pred;
+  read_cu(cu, depth, o);
+  g_yReco[depth] = r0; g_yPred[depth] = p0;
+}
+/* One intra CU candidate through the reference.  stage 2: TEncCu::xCheckRDCostIntra itself (TEncCu.cpp:2064-2157, the
+ * reference's function on a TEncCuRef object) against a best CU that has not seen a candidate yet, so the candidate always
+ * ends up in rpcBestCU after the function's own xCheckBestMode; the caller reads the coder from [depth][CI_TEMP_BEST], where
+ * the function stored it.  stage 1 = luma search only (estIntraPredLumaQT, BASELINE configs[1]).  The caller has loaded the
+ * picture state the search reads: PicYuvOrg, PicYuvRec (ref_set_org / ref_set_rec), the CTUs' decided arrays
+ * (ref_set_ctu_field) and the coder slot [depth][CI_CURR_BEST] (ref_coder_set). */
 int ref_intra_cu(int ctu, int zidx, int depth, int partSize, int stage, RefCuOut *out)
 {
+  if (stage >= 2) {
+    cu_ref_setup();
+    cu_ref_position(ctu, zidx, depth);
+    entropy_to_goon();
+    g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);                                   /* TEncSlice.cpp:1417 / TEncCu.cpp:1343-1347 */
+    TComDataCU *&best = g_cuRef->m_ppcBestCU[depth], *&temp = g_cuRef->m_ppcTempCU[depth];
+    Double cost = 0;
+    g_cuRef->xCheckRDCostIntra(best, temp, cost, PartSize(partSize));
+    read_cu_ref(best, depth, g_cuRef->m_ppcRecoYuvBest[depth], g_cuRef->m_ppcPredYuvBest[depth], out);
+    {                                                            /* the luma share of the distortion: SSE of the winning luma reconstruction (unweighted, TComRdCost.cpp:433-455) */
+      const TComYuv *o = g_cuRef->m_ppcOrigYuv[depth], *r = g_cuRef->m_ppcRecoYuvBest[depth];
+      const Pel *po = o->getAddr(COMPONENT_Y), *pr = r->getAddr(COMPONENT_Y); const int so = o->getStride(COMPONENT_Y), sr = r->getStride(COMPONENT_Y), w = 64 >> depth;
+      unsigned sse = 0;
+      for (int y = 0; y < w; y++) for (int x = 0; x < w; x++) { const int e = po[y * so + x] - pr[y * sr + x]; sse += (unsigned)(e * e); }
+      out->dist_luma = sse;
+    }
+    return 0;
+  }
   TComDataCU *cu = position_cu(ctu, zidx, depth);
   entropy_to_goon();
   g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);                                     /* TEncSlice.cpp:1417 / TEncCu.cpp:1343-1347 */
@@ -553,22 +615,17 @@ void ref_set_ctu_inter(int ctu, const unsigned char *skip, const unsigned char *
     f->m_pcMv[i].set(mv[2 * i], mv[2 * i + 1]); f->m_piRefIdx[i] = refIdx[i];
   }
 }
-/* One inter candidate through the reference: the body of TEncCu::xCheckRDCostInter (TEncCu.cpp:2025-2062) */
+/* One inter candidate through the reference: TEncCu::xCheckRDCostInter itself (TEncCu.cpp:2025-2062) on a TEncCuRef object */
 int ref_inter_cu(int ctu, int zidx, int depth, int partSizeArg, RefCuOut *out)
 {
   const int partSize = partSizeArg & 15; const bool useMRG = ((partSizeArg >> 4) & 1) != 0;       /* bit 4: bUseMRG (AMP_MRG: merge estimation only) */
-  TComDataCU *cu = position_cu(ctu, zidx, depth);
+  cu_ref_setup();
+  cu_ref_position(ctu, zidx, depth);
   entropy_to_goon();
   g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);
-  g_yOrg[depth]->copyFromPicYuv(g_pic->getPicYuvOrg(), ctu, zidx);
-  cu->setPartSizeSubParts(PartSize(partSize), 0, depth);
-  cu->setPredModeSubParts(MODE_INTER, 0, depth);
-  cu->setChromaQpAdjSubParts(0, 0, depth);
-  cu->setMergeAMP(true);
-  g_search->predInterSearch(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yReco[depth], false, useMRG);
-  g_search->encodeResAndCalcRdInterCU(cu, g_yOrg[depth], g_yPred[depth], g_yResi[depth], g_yResiBest[depth], g_yReco[depth], false);
-  cu->getTotalCost() = g_rd->calcRdCost(cu->getTotalBits(), cu->getTotalDistortion());
-  read_cu(cu, depth, out);
+  TComDataCU *&best = g_cuRef->m_ppcBestCU[depth], *&temp = g_cuRef->m_ppcTempCU[depth];
+  g_cuRef->xCheckRDCostInter(best, temp, PartSize(partSize), useMRG);      /* the reference's function; the fresh best CU loses to any candidate */
+  read_cu_ref(best, depth, g_cuRef->m_ppcRecoYuvBest[depth], g_cuRef->m_ppcPredYuvBest[depth], out);
   out->dist_luma = 0;
   return 0;
 }
@@ -692,6 +749,43 @@ void ref_adapter_planes_roundtrip(int comp, const unsigned char *in, unsigned ch
   const ComponentID c = ComponentID(comp);
   for (UInt a = 0; a < g_pic->getNumberOfCtusInFrame(); a++) fcu_adapter::widen_ctu_block(in, g_pic->getPicYuvRec(), c, a, g_pic->getFrameWidthInCtus());
   fcu_adapter::narrow_plane(g_pic->getPicYuvRec(), c, out);
+}
+
+/* flags: bit 0 P slice, bit 1 AMP enabled.  log[k] = (call id << 8) | changed flag of xCheckBestMode where the call returns it
+ * (intra), call ids: 1 merge, 2 inter (part size in bits 16..19, bUseMRG bit 20), 3 intra.  Returns the number of calls. */
+int ref_cu_run(int ctu, int zidx, int depth, int parentPartSize, int flags, RefCuOut *out, int *log)
+{
+  cu_ref_setup();
+  const bool isP = (flags & 1) != 0, amp = (flags & 2) != 0;
+  cu_ref_position(ctu, zidx, depth);
+  entropy_to_goon();
+  g_goOn->load(g_rdSbac[depth][CI_CURR_BEST]);
+  TComDataCU *&best = g_cuRef->m_ppcBestCU[depth], *&temp = g_cuRef->m_ppcTempCU[depth];
+  int n = 0;
+  bool tryIntra = true;
+  if (isP) {
+    Bool esd = false;
+    g_cuRef->xCheckRDCostMerge2Nx2N(best, temp, &esd); temp->initEstData(depth, g_qp, false); log[n++] = 1 << 8;      /* TEncCu.cpp:774-775 */
+    g_cuRef->xCheckRDCostInter(best, temp, SIZE_2Nx2N, false); temp->initEstData(depth, g_qp, false); log[n++] = (2 << 8) | (SIZE_2Nx2N << 16);   /* :780 */
+    g_cuRef->xCheckRDCostInter(best, temp, SIZE_Nx2N, false); temp->initEstData(depth, g_qp, false); log[n++] = (2 << 8) | (SIZE_Nx2N << 16);     /* :826 */
+    g_cuRef->xCheckRDCostInter(best, temp, SIZE_2NxN, false); temp->initEstData(depth, g_qp, false); log[n++] = (2 << 8) | (SIZE_2NxN << 16);     /* :835 */
+    if (amp && depth < 3) {                                       /* :843-943 (AMP_ENC_SPEEDUP, AMP_MRG) */
+      Bool hor = false, ver = false, mhor = false, mver = false;
+      g_cuRef->deriveTestModeAMP(best, PartSize(parentPartSize), hor, ver, mhor, mver);
+      const PartSize hs[2] = { SIZE_2NxnU, SIZE_2NxnD }, vs[2] = { SIZE_nLx2N, SIZE_nRx2N };
+      if (hor || mhor) for (int k = 0; k < 2; k++) { g_cuRef->xCheckRDCostInter(best, temp, hs[k], !hor); temp->initEstData(depth, g_qp, false); log[n++] = (2 << 8) | (hs[k] << 16) | ((!hor) << 20); }
+      if (ver || mver) for (int k = 0; k < 2; k++) { g_cuRef->xCheckRDCostInter(best, temp, vs[k], !ver); temp->initEstData(depth, g_qp, false); log[n++] = (2 << 8) | (vs[k] << 16) | ((!ver) << 20); }
+    }
+    tryIntra = best->getCbf(0, COMPONENT_Y) != 0 || best->getCbf(0, COMPONENT_Cb) != 0 || best->getCbf(0, COMPONENT_Cr) != 0;   /* :1033-1036 */
+  }
+  if (tryIntra) {
+    Double cost = 0;
+    Bool ch = g_cuRef->xCheckRDCostIntra(best, temp, cost, SIZE_2Nx2N); temp->initEstData(depth, g_qp, false); log[n++] = (3 << 8) | (SIZE_2Nx2N << 16) | (ch ? 1 : 0);   /* :1040 */
+    if (depth == 3) { ch = g_cuRef->xCheckRDCostIntra(best, temp, cost, SIZE_NxN); temp->initEstData(depth, g_qp, false); log[n++] = (3 << 8) | (SIZE_NxN << 16) | (ch ? 1 : 0); }   /* :1143 */
+  }
+  read_cu_ref(best, depth, g_cuRef->m_ppcRecoYuvBest[depth], g_cuRef->m_ppcPredYuvBest[depth], out);
+  out->dist_luma = 0;
+  return n;
 }
 
 /* ---- the fork's pre-pass: TEncSlice::getOutlierWithDCT (TEncSlice.cpp:878-1173), the reference's own member function.
