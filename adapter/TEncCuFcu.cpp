@@ -110,6 +110,9 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     fp.fast_search = cfg->getFastSearch() ? 1 : 0;
     fp.tmvp = slice->getEnableTMVPFlag() ? 1 : 0;
     fp.amp = slice->getSPS()->getUseAMP() ? 1 : 0;              /* part sizes 4..7 come back with HM's own PartSize values */
+    /* cabac_init_flag: the RD coders of this slice were reset with the table TEncSbac::determineCabacInitIdx chose after the
+     * previous slice (TEncSlice.cpp:1750-1753 -> TComSlice::getEncCABACTableIdx, TEncSbac::resetEntropy TEncSbac.cpp:111-115) */
+    fp.cabac_b_table = (pps->getCabacInitPresentFlag() && slice->getEncCABACTableIdx() == B_SLICE) ? 1 : 0;
   }
   int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
   if (rc != FCU_OK) die("fcu_chain_begin", rc);

@@ -213,6 +213,7 @@ struct Params {
   int amp;                     /* asymmetric motion partitions (AMP with AMP_ENC_SPEEDUP + AMP_MRG, TEncCu.cpp:381-450,836-943) */
   int rdoq, rdoq_ts;           /* RDOQ / RDOQTS: 0 = the plain quantiser of xQuant (quant_plain) for blocks without / with transform skip */
   uint32_t lambda_motion_sad;  /* m_uiLambdaMotionSAD = floor(65536 * sqrt(lambda)), TComRdCost.cpp:194-219 */
+  int cabac_b_table;           /* P slice initialised from the B-slice context tables (encCABACTableIdx == B_SLICE, TEncSbac.cpp:111-115) */
 };
 
 /* per-chain descriptor in HBM */
@@ -446,11 +447,11 @@ FCU_DEV int tu_nparts_c(const TU &t) { return t.c_code_all ? t.nparts : t.nparts
 /* ======================================================================================== */
 /* CABAC bit counter -- per-lane callable (TEncBinCoderCABACCounter.cpp:59-136)              */
 /* ======================================================================================== */
-FCU_DEV void cab_init(Cabac *c, int qp, int sliceType)   /* ContextModel::init, ContextModel.cpp:56-65; TEncSbac::resetEntropy :106-156 */
+FCU_DEV void cab_init(Cabac *c, int qp, int sliceType, int bTable)   /* ContextModel::init, ContextModel.cpp:56-65; TEncSbac::resetEntropy :106-156 */
 {
   if (qp < 0) qp = 0; if (qp > 51) qp = 51;
   for (int i = 0; i < NCTX; i++) {
-    int iv = sliceType == SLICE_P ? k_ctx_init_P[i] : k_ctx_init_I[i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
+    int iv = sliceType == SLICE_P ? (bTable ? k_ctx_init_B[i] : k_ctx_init_P[i]) : k_ctx_init_I[i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
     int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
     int mps = st >= 64;
     c->ctx[i] = (uint8_t)(((mps ? (st - 64) : (63 - st)) << 1) + mps);
@@ -2960,7 +2961,7 @@ FCU_DEV FCU_NOINLINE void compress_ctu(Chain *C, Scratch *G, int ctuRsAddr)
   E.cur_ctu = ctuRsAddr; E.slice_start = sliceStart;
   fcu_ctu_out *out = &C->out[ctuRsAddr];
   const int x = (ctuRsAddr % C->w_ctu) * CTU, y = (ctuRsAddr / C->w_ctu) * CTU;
-  FCU_SERIAL { g_S.env = E; if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp, P.slice_type); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
+  FCU_SERIAL { g_S.env = E; if (ctuRsAddr == sliceStart) cab_init(slot_ptr(E, 0, CI_CURR_BEST), P.qp, P.slice_type, P.cabac_b_table); else cab_copy1(slot_ptr(E, 0, CI_CURR_BEST), &C->state); }
   FCU_FOR_LANES {                                            /* TComDataCU::initCtu defaults, TComDataCU.cpp:474-560 */
     for (int i = lane; i < NPART; i += 64) {
       out->depth[i] = 0; out->width[i] = CTU; out->height[i] = CTU; out->skip[i] = 0; out->part_size[i] = SIZE_NONE; out->pred_mode[i] = MODE_NONE;

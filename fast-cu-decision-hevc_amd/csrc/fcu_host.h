@@ -15,6 +15,7 @@ inline void fill_params(Params &p, int width, int height, const fcu_frame_params
   p.width = width; p.height = height; p.qp = fp.qp; p.slice_ctus = fp.slice_ctus;
   p.slice_type = fp.slice_type; p.search_range = fp.search_range; p.fast_enc = fp.fast_enc; p.had_me = fp.hadamard_me;
   p.fast_search = fp.fast_search; p.rdoq = fp.rdoq; p.rdoq_ts = fp.rdoq_ts; p.tmvp = fp.tmvp; p.amp = fp.amp != 0;
+  p.cabac_b_table = fp.slice_type == FCU_SLICE_P && fp.cabac_b_table != 0;
   p.fdm = fp.fast_merge_decision; p.max_merge_cand = fp.max_merge_cand > 0 ? (fp.max_merge_cand > 5 ? 5 : fp.max_merge_cand) : 5;
   p.transform_skip = fp.transform_skip; p.ts_fast = fp.transform_skip_fast;
   p.sign_hiding = fp.sign_hiding; p.strong_smoothing = fp.strong_intra_smoothing;

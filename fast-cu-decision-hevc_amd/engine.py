@@ -28,7 +28,7 @@ class FrameParams(C.Structure):
                 ("lambda_", C.c_double), ("sqrt_lambda", C.c_double), ("chroma_weight", C.c_double),
                 ("rdoq_lambda", C.c_double * 3),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_enc", C.c_int), ("hadamard_me", C.c_int),
-                ("fast_merge_decision", C.c_int), ("max_merge_cand", C.c_int), ("fast_search", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("amp", C.c_int)]
+                ("fast_merge_decision", C.c_int), ("max_merge_cand", C.c_int), ("fast_search", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("amp", C.c_int), ("cabac_b_table", C.c_int)]
 
 
 class SeqParams(C.Structure):

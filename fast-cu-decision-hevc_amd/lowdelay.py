@@ -9,6 +9,13 @@ is chain s * n_slices + k.  Per picture: fcu_ldp_slice (QP / lambda of HM's lowd
 reference's lowdelay configuration; one batched call for all clips) -> fcu_pad_reference.
 Across GPUs the reference picture is the only data a rank would need from another one (one copy per picture, SURVEY.md 8e);
 with whole clips per rank there is none.
+
+Context-table choice of a P picture (cabac_init_flag): HM initialises a P slice from the B-slice tables when
+TEncSbac::determineCabacInitIdx picked them after the previous slice (TEncSlice.cpp:1750-1753).  That choice is made on the
+BITSTREAM coder's final state, which includes the SAO syntax and a per-context "bins were coded" flag the RD path does not
+carry; this driver therefore runs the configuration `CabacInitPresent 0` (every P picture starts from the P tables,
+cabac_b_table = 0) unless the caller names the table per picture (`cabac_b_table` below) -- the TAppEncoder adapter does,
+from TComSlice::getEncCABACTableIdx (adapter/TEncCuFcu.cpp).
 """
 import numpy as np
 
@@ -34,21 +41,23 @@ class LowDelayPDecider:
         self.poc = 0
         self.ref = [None] * n_clips                      # padded reference planes per clip
 
-    def frame_params(self, poc):
+    def frame_params(self, poc, cabac_b_table=0):
         fp = _engine.ldp_slice(self.base_qp, poc)
+        fp.cabac_b_table = 1 if (cabac_b_table and poc > 0) else 0
         fp.search_range = self.search_range
         fp.fast_search = self.fast_search
         fp.tmvp = 1 if (self.tmvp and poc > 0) else 0
         fp.amp = 1 if self.amp else 0
         return fp
 
-    def decide_picture(self, frames):
-        """frames: one (Y, U, V) per clip for picture self.poc.  Returns per clip a dict: poc, slice_type, qp, `out` (the
+    def decide_picture(self, frames, cabac_b_table=0):
+        """frames: one (Y, U, V) per clip for picture self.poc; cabac_b_table: 1 = this P picture starts from the B-slice
+        context tables (module docstring).  Returns per clip a dict: poc, slice_type, qp, `out` (the
         fcu_ctu_out array as a uint8 device tensor), `rec` (device planes after the loop filters that are enabled), `rec_unfiltered`
         (a copy before the loop filters, for parity checks), `sao` (the picture's fcu_sao_ctu array when SAO is on)."""
         eng, poc = self.eng, self.poc
         assert len(frames) == self.n_clips
-        fp = self.frame_params(poc)
+        fp = self.frame_params(poc, cabac_b_table)
         res = []
         for s, f in enumerate(frames):
             first = s * self.n_slices

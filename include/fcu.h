@@ -98,6 +98,10 @@ typedef struct fcu_frame_params {
                                     signBitHidingHDQ for blocks without / with transform skip */
   int amp;                       /* AMP: asymmetric motion partitions 2NxnU / 2NxnD / nLx2N / nRx2N at CU sizes 64..16, selected as
                                     HM does with AMP_ENC_SPEEDUP + AMP_MRG (TEncCu.cpp:381-450,836-943); part_size 4..7 in fcu_ctu_out */
+  int cabac_b_table;             /* P slice: 1 = its contexts start from the B-slice tables (TComSlice::getEncCABACTableIdx() == B_SLICE
+                                    with cabac_init_present_flag: TEncSbac::resetEntropy, TEncSbac.cpp:111-115 -- the choice
+                                    TEncSbac::determineCabacInitIdx made after the previous slice, TEncSlice.cpp:1750-1753); 0 = the
+                                    slice type's own tables */
 } fcu_frame_params;
 enum { FCU_SLICE_I = 0, FCU_SLICE_P = 1 };
 #define FCU_REF_MARGIN_LUMA 80   /* border of a padded reference plane: g_uiMaxCUWidth + 16 (TComPic::create); chroma: 40 */

@@ -121,6 +121,8 @@ typedef struct {
   int rdoq, rdoq_ts;            /* RDOQ / RDOQTS (1, 1): 0 = the plain quantiser of xQuant with signBitHidingHDQ */
   double lambda_override;       /* > 0: slice lambda given by the caller (P-slice QP factor, TEncSlice.cpp:686-706) */
   unsigned lambda_motion_sad, lambda_motion_sse;   /* m_uiLambdaMotionSAD / SSE, TComRdCost.cpp:194-219 */
+  int cabac_b_table;            /* P slice initialised from the B-slice context tables: TComSlice::getEncCABACTableIdx() == B_SLICE with
+                                   cabac_init_present_flag (TEncSbac::resetEntropy, TEncSbac.cpp:111-115) */
 } HmoParams;
 
 /* Per-CTU decisions, TComDataCU layout (TComDataCU.h:72-164).  One entry
@@ -217,6 +219,7 @@ void    hmo_filter_ref(const uint8_t *ref, uint8_t *out, int n, int strong);
 int     hmo_use_filtered_ref(int mode, int log2, int isLuma);
 void    hmo_cabac_init(HmoCabac *c, int qp);                 /* I-slice tables */
 void    hmo_cabac_init_st(HmoCabac *c, int qp, int slice_type);
+void    hmo_cabac_init_tab(HmoCabac *c, int qp, int slice_type, int b_table);
 const int16_t *hmo_dct_matrix(int log2);   /* N*N, row-major */
 const uint16_t *hmo_scan(int scanType, int log2);
 const uint8_t *hmo_zscan_to_raster(void);

@@ -7,12 +7,14 @@
 
 /* ContextModel::init, ContextModel.cpp:56-65 ; TEncSbac::resetEntropy, TEncSbac.cpp:106-156 */
 void hmo_cabac_init(HmoCabac *c, int qp) { hmo_cabac_init_st(c, qp, HMO_SLICE_I); }
-void hmo_cabac_init_st(HmoCabac *c, int qp, int slice_type)
+void hmo_cabac_init_st(HmoCabac *c, int qp, int slice_type) { hmo_cabac_init_tab(c, qp, slice_type, 0); }
+void hmo_cabac_init_tab(HmoCabac *c, int qp, int slice_type, int b_table)
 {
   hmo_init_tables();
   if (qp < 0) qp = 0;
   if (qp > 51) qp = 51;
-  const uint8_t *tab = slice_type == HMO_SLICE_P ? hmo_ctx_init_P : hmo_ctx_init_I;   /* initType: cabac_init_flag 0 */
+  /* eSliceType = encCABACTableIdx for a non-intra slice when cabac_init_present_flag is set (TEncSbac.cpp:111-115) */
+  const uint8_t *tab = slice_type == HMO_SLICE_P ? (b_table ? hmo_ctx_init_B : hmo_ctx_init_P) : hmo_ctx_init_I;
   for (int i = 0; i < HMO_NCTX; i++) {
     int iv = tab[i];
     int slope = (iv >> 4) * 5 - 45;

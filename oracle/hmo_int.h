@@ -18,7 +18,7 @@ extern const int hmo_ang_table[9], hmo_inv_ang_table[9];
 extern const uint8_t hmo_intra_filter_thr[5], hmo_rd_mode_num[5];
 extern const uint8_t hmo_next_mps[128], hmo_next_lps[128];
 extern const int32_t hmo_entropy_bits[128];
-extern const uint8_t hmo_ctx_init_I[HMO_NCTX], hmo_ctx_init_P[HMO_NCTX];
+extern const uint8_t hmo_ctx_init_I[HMO_NCTX], hmo_ctx_init_P[HMO_NCTX], hmo_ctx_init_B[HMO_NCTX];
 void hmo_init_tables(void);
 
 /* Working copy of one CU's decisions (the per-depth TComDataCU best/temp objects,

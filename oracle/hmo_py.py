@@ -16,7 +16,7 @@ class Params(C.Structure):
                 ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
                 ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("amp", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
-                ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint)]
+                ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint), ("cabac_b_table", C.c_int)]
 
 
 class Ctu(C.Structure):

@@ -1086,7 +1086,7 @@ void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
   const int sliceStart = (ctuRsAddr / sliceLen) * sliceLen;
   int sliceEnd = sliceStart + sliceLen; if (sliceEnd > e->n_ctu) sliceEnd = e->n_ctu;
   e->cur_ctu = ctuRsAddr; e->slice_start = sliceStart;
-  if (ctuRsAddr == sliceStart) hmo_cabac_init_st(&e->slot[0][CI_CURR_BEST], e->p.qp, e->p.slice_type);     /* resetEntropy */
+  if (ctuRsAddr == sliceStart) hmo_cabac_init_tab(&e->slot[0][CI_CURR_BEST], e->p.qp, e->p.slice_type, e->p.cabac_b_table);     /* resetEntropy */
   pic_ctu_init(e, &e->pic[ctuRsAddr]);
   e->goon = e->slot[0][CI_CURR_BEST];
   e->goon_bins = 0;

@@ -667,6 +667,14 @@ void ref_set_amp(int on)
   TComSPS *sps = const_cast<TComSPS *>(g_slice->getSPS());
   sps->setUseAMP(on != 0); g_sps.setUseAMP(on != 0);
 }
+/* cabac_init_flag machinery: the table index the encoder chose after the previous slice (TEncSlice.cpp:1750-1753) reaches
+ * TEncSbac::resetEntropy through the slice (TEncSbac.cpp:111-115); cabac_init_present_flag must be on in the PPS */
+void ref_set_cabac_table(int bTable)
+{
+  TComPPS *pps = const_cast<TComPPS *>(g_slice->getPPS());
+  pps->setCabacInitPresentFlag(true); g_pps.setCabacInitPresentFlag(true);
+  g_slice->setEncCABACTableIdx(bTable ? B_SLICE : P_SLICE);
+}
 void ref_set_rdoq(int rdoq, int rdoqTS) { g_trq->m_useRDOQ = rdoq != 0; g_trq->m_useRDOQTS = rdoqTS != 0; }
 void ref_set_slice_type(int isP) { g_slice->setSliceType(isP ? P_SLICE : I_SLICE); }
 

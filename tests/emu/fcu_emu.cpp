@@ -64,6 +64,7 @@ void fcu_emu_set_decision(void *h, int state, const uint8_t *sw_skip, const uint
 }
 void fcu_emu_set_col(void *h, const fcu_ctu_out *col) { ((EmuChain *)h)->c.col = col; ((EmuChain *)h)->c.p.tmvp = col != nullptr; }
 void fcu_emu_set_amp(void *h, int amp) { ((EmuChain *)h)->c.p.amp = amp != 0; }
+void fcu_emu_set_cabac_b(void *h, int on) { ((EmuChain *)h)->c.p.cabac_b_table = on != 0; }
 void fcu_emu_set_rdoq(void *h, int rdoq, int rdoq_ts) { ((EmuChain *)h)->c.p.rdoq = rdoq; ((EmuChain *)h)->c.p.rdoq_ts = rdoq_ts; }
 void fcu_emu_set_pu_trace(void *h, fcu_pu_trace *buf) { ((EmuChain *)h)->c.pu_trace = buf; }
 void fcu_emu_get_verify(void *h, double *out24) { memcpy(out24, ((EmuChain *)h)->c.ver, sizeof(double) * 24); }

@@ -25,6 +25,7 @@ def load():
     lib.fcu_emu_get_state_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fcu_emu_set_rdoq.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fcu_emu_set_amp.argtypes = [C.c_void_p, C.c_int]
+    lib.fcu_emu_set_cabac_b.argtypes = [C.c_void_p, C.c_int]
     lib.fcu_emu_set_col.argtypes = [C.c_void_p, C.c_void_p]
     return lib
 
@@ -38,7 +39,7 @@ def pad_planes(planes):
 
 
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1, col=None, amp=0):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1, col=None, amp=0, cabac_b_table=0):
         """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda)"""
         self.lib = load()
         h, w = Y.shape
@@ -50,6 +51,7 @@ class EmuEncoder:
                                          *[a.ctypes.data for a in self.rec], C.addressof(self.out))
         self._rdoq = (rdoq, rdoq_ts)
         self._amp = amp
+        self._cabac_b = cabac_b_table
         self._col = None if col is None else np.frombuffer(bytes(col), dtype=np.uint8).copy()      # TMVP: the reference picture's Ctu array
         if ref is not None:
             self.pad = pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in ref])
@@ -67,6 +69,7 @@ class EmuEncoder:
     def compress_ctu(self, a):
         self.lib.fcu_emu_set_rdoq(self.h, *self._rdoq)           # (set_p / set_lambda rebuild the parameter block)
         self.lib.fcu_emu_set_amp(self.h, self._amp)
+        self.lib.fcu_emu_set_cabac_b(self.h, self._cabac_b)
         if self._col is not None:
             self.lib.fcu_emu_set_col(self.h, self._col.ctypes.data)
         self.lib.fcu_emu_compress_ctu(self.h, a)

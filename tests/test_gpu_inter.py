@@ -22,12 +22,13 @@ def _same_ctu(got, want, tag):
             assert v == got[k], f"{tag}: {k}: engine {got[k]} oracle {v}"
 
 
-@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,fast,tmvp,amp", [("mixed", 136, 72, 27, 3, 8, 0, 0, 0), ("textured", 192, 128, 32, 3, 16, 0, 0, 0), ("smooth", 128, 64, 37, 5, 64, 0, 0, 0),
+@pytest.mark.parametrize("gen,w,h,base_qp,n_pic,sr,fast,tmvp,amp,btab", [c + (0,) for c in [("mixed", 136, 72, 27, 3, 8, 0, 0, 0), ("textured", 192, 128, 32, 3, 16, 0, 0, 0), ("smooth", 128, 64, 37, 5, 64, 0, 0, 0),
                                                                         ("mixed", 136, 72, 27, 3, 16, 1, 0, 0), ("textured", 192, 128, 32, 3, 64, 1, 0, 0),      # fast = 1: TZ search (FastSearch 1)
                                                                         ("mixed", 192, 128, 30, 4, 16, 1, 1, 0), ("textured", 136, 72, 35, 4, 32, 0, 1, 0),     # tmvp = 1: temporal candidates
                                                                         ("shear_textured", 192, 128, 27, 3, 16, 1, 0, 1), ("shear_mixed", 136, 72, 32, 4, 32, 1, 1, 1),   # amp = 1: asymmetric partitions
-                                                                        ("mixed", 192, 128, 30, 3, 16, 0, 0, 1)])
-def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast, tmvp, amp):
+                                                                        ("mixed", 192, 128, 30, 3, 16, 0, 0, 1)]] +
+                         [("mixed", 136, 72, 30, 3, 16, 1, 1, 1, 1)])     # btab = 1: P pictures started from the B-slice context tables (cabac_init_flag)
+def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast, tmvp, amp, btab):
     """compressCtu-shaped calls: every CTU of every picture of a short lowdelay_P clip, CABAC state after every CTU."""
     eng = pkg.CuEngine(w, h, max_chains=1)
     prev, prev_pad, prev_out, prev_ctus = None, None, None, None
@@ -38,11 +39,12 @@ def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast, tmvp, a
         fp.fast_search = fast
         fp.tmvp = 1 if (tmvp and poc) else 0
         fp.amp = amp
+        fp.cabac_b_table = 1 if (btab and poc) else 0
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
         assert fp.qp == qp and fp.lambda_ == lam and fp.slice_type == (0 if poc == 0 else 1)
         eng.init_chain(0, f, fp.qp, params=fp, ref=prev_pad, col=prev_out if (tmvp and poc) else None)
         ref = hmo_py.Encoder(*f, qp, lambda_override=lam) if poc == 0 else \
-            hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
+            hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp, cabac_b_table=btab)
         for a in range(eng.n_ctu):
             got = eng.compress_ctu(0, a)
             ref.compress_ctu(a)

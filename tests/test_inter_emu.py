@@ -95,6 +95,44 @@ def test_emulated_engine_p_pictures(case, built, pkg):
         assert n_amp > 0                                         # asymmetric partitions survive into the decided pictures
 
 
+def test_p_slice_started_from_the_b_tables(built, pkg):
+    """cabac_init_flag: a P picture whose contexts start from the B-slice tables (the encoder's choice after the previous
+    slice, TEncSbac.cpp:111-115).  The initial states of both tables are pinned by the reference's own resetEntropy at every
+    QP (tests/golden/cabac_init.npz, oracle/ref/make_golden_cabac_init.py); the engine source on the wave emulator follows
+    the oracle through a P picture started that way -- and decides differently from the same picture started from the P
+    tables."""
+    import ctypes as C
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cabac_init.npz"))["states"]
+    lib = hmo_py.load()
+    for qp in range(52):
+        for k, (stype, b) in enumerate(((hmo_py.SLICE_I, 0), (hmo_py.SLICE_P, 0), (hmo_py.SLICE_P, 1))):
+            c = hmo_py.Cabac()
+            lib.hmo_cabac_init_tab(C.byref(c), qp, stype, b)
+            idx = st.O_SORTED if k else st.O_SORTED[st.O_SORTED < 159]
+            assert np.array_equal(np.ctypeslib.as_array(c.ctx)[idx], g[qp, k][idx]), (qp, k)
+    assert (g[32, 1] != g[32, 2]).sum() > 30
+    w, h, base_qp, sr = 128, 64, 30, 8
+    f0, f1 = st.moving_frame(pkg.synth, "mixed", w, h, 5, 0), st.moving_frame(pkg.synth, "mixed", w, h, 5, 1)
+    _, qp0, lam0 = hmo_py.ldp_slice(0, base_qp)
+    o = hmo_py.Encoder(*f0, qp0, lambda_override=lam0)
+    o.compress_frame(); o.deblock()
+    prev = [a.copy() for a in o.rec]
+    _, qp, lam = hmo_py.ldp_slice(1, base_qp)
+    states = {}
+    for b in (0, 1):
+        o = hmo_py.Encoder(*f1, qp, ref=prev, lambda_override=lam, search_range=sr, fast_search=1, cabac_b_table=b)
+        e = emu_py.EmuEncoder(*f1, qp, ref=prev, lam=lam, search_range=sr, fast_search=1, cabac_b_table=b)
+        for a in range(o.n_ctu):
+            o.compress_ctu(a); e.compress_ctu(a)
+            A, B = o.ctu_arrays(a), e.ctu_arrays(a)
+            for k, v in A.items():
+                assert (np.array_equal(v, B[k]) if isinstance(v, np.ndarray) else v == B[k]), (b, a, k)
+            (ca, fa), (cb, fb) = o.cabac(full=True), e.cabac(full=True)
+            assert fa == fb and np.array_equal(ca[st.O_SORTED], cb[st.O_SORTED]), (b, a, "CABAC state")
+        states[b] = (o.cabac(full=True), [o.ctu_arrays(a)["total_bits"] for a in range(o.n_ctu)])
+    assert states[0][1] != states[1][1] or not np.array_equal(states[0][0][0], states[1][0][0])
+
+
 def test_random_small_clips_on_the_emulator(built, pkg):
     """A CPU-side slice of tests/parity_sweep_ldp.py: random small lowdelay clips (global or sheared motion, QP, search range,
     TZ / full search, TMVP, AMP, slices) through the engine source on the wave emulator against the oracle, every field of
