@@ -35,21 +35,31 @@ ALGO_BYTES_PER_CTU = 55300          # src 12288 + neighbours 102
 # two chroma blocks with their interpolation margin 2 x (32 + 8)^2 -- SURVEY.md 8(d) gives no figure for configs[4]; DESIGN.md 3e
 algo_bytes_ldp = lambda sr: ALGO_BYTES_PER_CTU + (64 + 2 * sr) ** 2 + 2 * (32 + 8) ** 2
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_SUMMARY = {"intra": os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "ldp": os.path.join(ROOT, "profiles", "r02_pmc_summary_ldp.json")}
+PMC_SUMMARY = {"intra": os.path.join(ROOT, "profiles", "r03_pmc_summary.json"), "ldp": os.path.join(ROOT, "profiles", "r03_pmc_summary_ldp.json")}
+# wave instructions the chip's SIMDs can issue per second at the spec clock: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64
+# VALU instruction (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cycles on a SIMD-32)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
 
 
-def measured_traffic(config, chains, ctus_per_step):
-    """HBM-side bytes per launch of the engine kernel from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and the
-    commit the profiled library was built from.  None when the summary is for another workload shape."""
+def measured_counters(config, chains):
+    """Per-CTU figures of the engine kernel from the committed rocprofv3 PMC passes of this bench (profiles/r03_pmc_summary*.json,
+    folded by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950; SQ_WAIT_ANY / SQ_WAVE_CYCLES; SQ_INSTS_VALU) and the commit the profiled library was built from.
+    The counters scale with the CTUs a launch decides, so they are kept per CTU and apply to any number of CTUs per step;
+    they are only attached when the profiled run had the same number of chains in flight (waits depend on it)."""
     try:
         with open(PMC_SUMMARY[config]) as f:
             d = json.load(f)
-        if d.get("config") != config or d.get("chains_per_launch") != chains or d.get("ctus_per_chain_per_launch") != ctus_per_step:
-            return None, None
-        return float(d["traffic_bytes_per_launch"]), d.get("commit")
-    except (OSError, ValueError, KeyError):
-        return None, None
+        if d.get("config") != config or d.get("chains_per_launch") != chains:
+            return None
+        per_launch = d["chains_per_launch"] * d["ctus_per_chain_per_launch"]
+        c = d.get("counters_per_launch", {})
+        return {"traffic_bytes_per_ctu": float(d["traffic_bytes_per_ctu"]), "wait_share": d.get("wait_share_of_wave_cycles"),
+                "valu_per_ctu": (c["SQ_INSTS_VALU"] / per_launch) if "SQ_INSTS_VALU" in c else None,
+                "salu_per_ctu": (c["SQ_INSTS_SALU"] / per_launch) if "SQ_INSTS_SALU" in c else None,
+                "l2_hit_rate": d.get("l2_hit_rate"), "commit": d.get("commit")}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
 
 
 def gen_textured_gpu(torch, dev, w, h, seed, shift=(0, 0)):
@@ -115,7 +125,7 @@ def cpu_leg(make_encoder, first_ctu, gpu_lookup, budget_s, label):
     return n, dt, same, total, label
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -138,8 +148,12 @@ def main():
                     help="fork state of the timed steps (intra).  training (default, the headline metric): exhaustive RDO.  testing: "
                          "the fork's Naive pruning; OBF maps from the device pre-pass, the first warm-up step runs in the Verifying "
                          "state and its counters set the per-depth switches (SetDecisionSwitch)")
-    args = ap.parse_args()
+    ap.add_argument("--no-ldp-leg", action="store_true", help="default intra run on one GPU: skip the short lowdelay_P measurement reported under \"ldp\" in the same JSON line")
+    return ap.parse_args(argv)
 
+
+def run(args, emit=True):
+    """One measurement (args.config) -> the result dict on rank 0 (None elsewhere); printed as the JSON line when `emit`."""
     import numpy as np
     import torch
     import __graft_entry__ as g
@@ -289,7 +303,9 @@ def main():
         per_launch = timed_ctus_gpu / max(1, args.steps)
         algo = algo_bytes_ldp(args.search_range) if ldp else ALGO_BYTES_PER_CTU
         achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, prof_commit = measured_traffic(args.config, n_chains, cps) if (switches is None and not args.amp and not args.shear) else (None, None)
+        pmc = measured_counters(args.config, n_chains) if (switches is None and not args.amp and not args.shear and world == 1) else None
+        traffic = pmc["traffic_bytes_per_ctu"] * per_launch if pmc else None
+        kernel_ctus_per_s = per_launch / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
         what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
                 f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
                 f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}{'; sheared motion (--shear 1)' if args.shear else ''}" if ldp else
@@ -309,9 +325,18 @@ def main():
                        "state": args.state if switches is None else
                        f"testing (Naive switches skip2Nx2N={switches[0].tolist()} terminate={switches[1].tolist()} from a Verifying step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profile_commit": prof_commit,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_bytes_per_ctu": pmc["traffic_bytes_per_ctu"] if pmc else None,
+                         "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
+                         "traffic_profile_commit": pmc["commit"] if pmc else None,
                          "kernel": "fcu_ctu_engine", "kernel_ms": kernel_ms, "launches": launches, "algorithmic_bytes_per_ctu": algo,
-                         "note": "`achieved` counts algorithmic bytes only; the kernel moves about %s TB/s of chain-private scratch (see `traffic`) and is bound by the latency of dependent accesses in the serial CABAC / RDOQ code of each chain: DESIGN.md 3" % ("2.9" if ldp else "1.8")},
+                         # what actually limits the kernel (`bound` above is the nominal roofline BASELINE asks for)
+                         "limit": "latency: instruction issue of one serial stream per chain (RDOQ / CABAC bit counting), each wave waiting on memory for about wait_share of its cycles",
+                         "wait_share": pmc["wait_share"] if pmc else None,
+                         "valu_instructions_per_ctu": pmc["valu_per_ctu"] if pmc else None,
+                         "valu_issue_frac": (pmc["valu_per_ctu"] * kernel_ctus_per_s / VALU_ISSUE_PEAK) if (pmc and pmc["valu_per_ctu"]) else None,
+                         "note": "`achieved` counts algorithmic bytes only; `traffic` = HBM-side bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per CTU from the committed PMC "
+                                 "passes of this bench, times the CTUs of a launch); `valu_issue_frac` = VALU wave instructions retired per second over 256 CUs x 4 SIMDs x 2.4 GHz / 2: DESIGN.md 3"},
         }
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         if world == 1 and not args.no_cpu_baseline:
@@ -380,10 +405,46 @@ def main():
                 sweep[str(n)] = n * k / (time.perf_counter() - t1)
             res["chains_sweep"] = {"ctus_per_sec": sweep, "ctus_per_chain": k,
                                    "note": "first CTUs of the first n chains (lowest QP first), one launch each; one chain = one wavefront"}
-        print(json.dumps(res), flush=True)
+            if not ldp and n_sl > 1:
+                # (d) the reference's own slice configuration (SliceMode 0: one slice per picture, so one chain per (frame, QP)):
+                # what a stream that cannot be cut into slices sees -- reported next to the SliceMode-1 headline, never as it
+                n1 = min(len(seeds) * len(qps), 480)
+                pairs = [(seed, qp) for qp in qps for seed in seeds][:n1]
+                for ci, (seed, qp) in enumerate(pairs):
+                    eng.init_chain(ci, frames[seed], qp=qp, slice_ctus=0, rec=recs[(seed, qp)], out=outs[(seed, qp)])
+                eng.sync()
+                t1 = time.perf_counter()
+                eng.compress_chains(0, n1, k)
+                eng.sync()
+                res["slice_mode_0"] = {"chains": n1, "ctus_per_sec": n1 * k / (time.perf_counter() - t1), "ctus_per_chain": k,
+                                       "note": "one slice per picture (the reference cfg's SliceMode 0): one chain per (frame, QP); a chain advances about "
+                                               "5 CTUs/s, so throughput is the number of independent pictures in flight times that"}
     eng.destroy()
+    del frames, recs, outs, refs
+    torch.cuda.empty_cache()
+    if rank == 0 and emit:
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return res if rank == 0 else None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.config != "intra" or world > 1 or args.no_ldp_leg or args.state != "training":
+        run(args)
+        return
+    # the default command (the driver's): the intra measurement is the JSON line; a short lowdelay_P measurement (BASELINE
+    # configs[4], the shape of `--config ldp`: 240 clips x 17 slices, TZ search, AMP off, fewer steps) rides under "ldp"
+    res = run(args, emit=False)
+    a2 = parse_args(["--config", "ldp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"])
+    ldp = run(a2, emit=False)
+    res["ldp"] = {k: ldp[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step")}
+    res["ldp"]["workload"] = ldp["config"]["workload"]
+    res["ldp"]["timed_ctu_range"] = ldp["config"]["timed_ctu_range"]
+    res["ldp"]["roofline"] = ldp["roofline"]
+    print(json.dumps(res), flush=True)
 
 
 def _unpad(padded, w, h):

@@ -98,21 +98,25 @@ def test_ldp_416x240_clip_matches_oracle_and_reference_loop_filter(pkg):
     dec.close()
 
 
-@pytest.mark.parametrize("gen,fast,amp,rows", [("textured", 0, 0, (0, 17, 33)), ("shear_textured", 1, 1, (0, 16, 33))])
-def test_4k_pair_ctu_rows(pkg, gen, fast, amp, rows):
+@pytest.mark.parametrize("gen,fast,amp,rows,sr,tmvp", [("textured", 0, 0, (0, 17, 33), 16, 0), ("shear_textured", 1, 1, (0, 16, 33), 16, 0),
+                                                       ("textured", 1, 0, (17,), 64, 0), ("shear_textured", 1, 1, (9, 33), 64, 1)])
+def test_4k_pair_ctu_rows(pkg, gen, fast, amp, rows, sr, tmvp):
     """BASELINE configs[4] at full size: a 3840x2160 picture pair.  Picture 0 (intra) is decided, deblocked and padded on
-    the GPU (that path has its own 4K parity test); picture 1 (P, one CTU row per slice, SearchRange 16 to bound the
-    oracle's CPU time) is compared with the oracle on the top row, an interior row and the partial bottom row.  Second
-    case: TZ search + asymmetric partitions on content whose motion boundaries sit on CU quarters."""
-    w, h, base_qp, sr, sl = 3840, 2160, 32, 16, 60
-    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl, fast_search=fast, amp=bool(amp))
+    the GPU (that path has its own 4K parity test); picture 1 (P, one CTU row per slice) is compared with the oracle on
+    whole CTU rows: top, interior and the partial bottom row at SearchRange 16 with the full search and with TZ search +
+    asymmetric partitions (content whose motion boundaries sit on CU quarters); an interior row at the bench's and the
+    reference cfg's SearchRange 64 with TZ search; an interior and the bottom row at SearchRange 64 with TZ + AMP + TMVP (the
+    collocated picture = picture 0's fcu_ctu_out array in HBM)."""
+    w, h, base_qp, sl = 3840, 2160, 32, 60
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl, fast_search=fast, amp=bool(amp), tmvp=bool(tmvp))
     f0 = st.moving_frame(pkg.synth, gen, w, h, 7, 0)
     r0 = dec.decide_picture([f0])[0]
     prev = [p.cpu().numpy() for p in r0["rec"]]
     f1 = st.moving_frame(pkg.synth, gen, w, h, 7, 1)
     r1 = dec.decide_picture([f1])[0]
     _, qp, lam = hmo_py.ldp_slice(1, base_qp)
-    ref = hmo_py.Encoder(*f1, qp, slice_ctus=sl, ref=prev, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
+    col = bytes(r0["out"].cpu().numpy()) if tmvp else None
+    ref = hmo_py.Encoder(*f1, qp, slice_ctus=sl, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
     n_inter = 0
     for row in rows:
         for a in range(row * 60, row * 60 + 60):
