@@ -113,3 +113,9 @@ def test_ranks_never_share_a_frame(pkg):
             assert len(mine) == frames * 4 and len(set(mine)) == len(mine)
             assert not (seen & set(mine))
             seen |= set(mine)
+
+
+def test_exchange_head_is_the_decision_part_of_a_ctu_record(pkg):
+    """sharding.merge_picture sends the head of every fcu_ctu_out record: exactly the bytes in front of the coefficient arrays"""
+    assert pkg.engine.CtuOut.coeff_y.offset == pkg.sharding.CTU_HEAD_BYTES
+    assert pkg.engine.CtuOut.mvd.offset + pkg.engine.CtuOut.mvd.size == pkg.sharding.CTU_HEAD_BYTES

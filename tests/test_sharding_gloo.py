@@ -1,5 +1,6 @@
 """N>1 path on CPU: two gloo ranks each decide their own shard of chains (with the emulated engine) and
 the union equals the single-process result; the step time is the MAX over ranks."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -89,10 +90,18 @@ for poc in range(n_pic):
             e.compress_ctu(a)
     planes = [torch.from_numpy(p) for p in e.rec]              # share memory with the emulator's planes / output array
     out = torch.from_numpy(np.frombuffer(e.out, dtype=np.uint8))
-    pkg.sharding.merge_picture(dist, planes, out)              # the one collective of the picture
+    planes = [p.view(h >> (1 if k else 0), w >> (1 if k else 0)) for k, p in enumerate(planes)]
+    nb = C.sizeof(hmo_py.Ctu)
+    pkg.sharding.merge_picture(dist, planes, out, sl, nb)      # the one exchange of the picture: own samples + decision heads
     dbk_emu(e.out, e.rec, w, h)                                # every rank filters the whole picture itself
     prev = [p.copy() for p in e.rec]
-    crcs.append([zlib.crc32(p.tobytes()) for p in e.rec] + [zlib.crc32(bytes(e.out))])
+    v = np.frombuffer(e.out, dtype=np.uint8).reshape(n_ctu, nb)
+    own = np.zeros(n_ctu, bool)
+    for first, n in mine:
+        own[first:first + n] = True
+    # planes and decision heads of the whole picture; whole records (coefficients, totals) of this rank's own CTUs
+    crcs.append([zlib.crc32(p.tobytes()) for p in e.rec] + [zlib.crc32(v[:, :pkg.sharding.CTU_HEAD_BYTES].tobytes())] +
+                [zlib.crc32(v[a].tobytes()) if own[a] else -1 for a in range(n_ctu)])
 t = torch.tensor(crcs, dtype=torch.int64)
 got = [torch.zeros_like(t) for _ in range(world)]
 dist.all_gather(got, t)
@@ -104,8 +113,9 @@ dist.destroy_process_group()
 
 def test_slices_of_a_lowdelay_clip_over_two_ranks(built, pkg, tmp_path):
     """bench.py --shard slices / the inter reference hand-off: slices of every picture of a lowdelay_P clip decided on two
-    ranks (engine source on the CPU), one merge_picture all-reduce per picture, loop filter replicated -- every rank ends
-    every picture with the planes and decisions of the single-process run."""
+    ranks (engine source on the CPU), one merge_picture exchange per picture (each rank broadcasts the samples and the
+    decision heads of its own CTUs), loop filter replicated -- every rank ends every picture with the planes and decisions of
+    the single-process run; the coefficient arrays stay with the rank that produced them."""
     import json
     import zlib
     import emu_py
@@ -120,7 +130,8 @@ def test_slices_of_a_lowdelay_clip_over_two_ranks(built, pkg, tmp_path):
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT "):])
-    assert got[0] == got[1]                                    # both ranks hold the same pictures
+    head_n = 4                                                 # three planes + the decision heads: the same on both ranks
+    assert [r[:head_n] for r in got[0]] == [r[:head_n] for r in got[1]]
     w, h, base_qp, sl, sr, n_pic = 192, 128, 30, 2, 8, 3
     prev = None
     for poc in range(n_pic):
@@ -130,4 +141,9 @@ def test_slices_of_a_lowdelay_clip_over_two_ranks(built, pkg, tmp_path):
         e.compress_frame()
         dbk_emu(e.out, e.rec, w, h)
         prev = [p.copy() for p in e.rec]
-        assert got[0][poc] == [zlib.crc32(p.tobytes()) for p in e.rec] + [zlib.crc32(bytes(e.out))], poc
+        v = np.frombuffer(e.out, dtype=np.uint8).reshape(-1, C.sizeof(hmo_py.Ctu))
+        assert got[0][poc][:head_n] == [zlib.crc32(p.tobytes()) for p in e.rec] + [zlib.crc32(v[:, :pkg.sharding.CTU_HEAD_BYTES].tobytes())], poc
+        whole = [zlib.crc32(v[a].tobytes()) for a in range(len(v))]
+        for a in range(len(v)):                                  # every CTU's whole record (levels, totals) lives on exactly its owner
+            owners = [r for r in range(2) if got[r][poc][head_n + a] != -1]
+            assert len(owners) == 1 and got[owners[0]][poc][head_n + a] == whole[a], (poc, a)
