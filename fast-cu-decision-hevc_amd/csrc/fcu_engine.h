@@ -718,10 +718,13 @@ FCU_DEV int ic_rate(const LevelBits &b, uint32_t absLevel, uint32_t goRice, uint
   else rate = 0;
   return rate;
 }
+/* rateHi / rateLo: xGetICRate of the two levels tried, maxAbsLevel and maxAbsLevel - 1 (rateLo only when that level is >= 1).
+ * The caller needs the rates of the chosen level and of its two neighbours afterwards (rateIncUp / rateIncDown,
+ * TComTrQuant.cpp:2263-2270): two of those three are among the values computed here. */
 template <class CB>
 FCU_DEV uint32_t coded_level(CB cb, double lambda, double *codedCost, double *codedCost0, double *codedCostSig,
                              int32_t levelDouble, uint32_t maxAbsLevel, int ctxSig, const LevelBits &lb,
-                             uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last)
+                             uint32_t goRice, uint32_t c1Idx, uint32_t c2Idx, int qbits, double errScale, int last, int *rateHi, int *rateLo)
 {                                                          /* xGetCodedLevel, TComTrQuant.cpp:2738-2794 */
   double currCostSig = 0; uint32_t bestAbs = 0;
   if (!last && maxAbsLevel < 3) {
@@ -733,7 +736,9 @@ FCU_DEV uint32_t coded_level(CB cb, double lambda, double *codedCost, double *co
   const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
   for (int a = (int)maxAbsLevel; a >= (int)minAbs; a--) {
     double err = (double)(levelDouble - ((int32_t)a << qbits));
-    double cost = err * err * errScale + lambda * (double)ic_rate(lb, (uint32_t)a, goRice, c1Idx, c2Idx);
+    const int rate = ic_rate(lb, (uint32_t)a, goRice, c1Idx, c2Idx);
+    if (a == (int)maxAbsLevel) *rateHi = rate; else *rateLo = rate;
+    double cost = err * err * errScale + lambda * (double)rate;
     cost += currCostSig;
     if (cost < *codedCost) { bestAbs = (uint32_t)a; *codedCost = cost; *codedCostSig = currCostSig; }
   }
@@ -903,18 +908,23 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
         } else {
           const int absCtx = CTX_ABS + (int)ctxSet + c2;
           LevelBits lb; lb.g10 = g10; lb.g11 = cb(oneCtx, 1); lb.g20 = cb(absCtx, 0); lb.g21 = cb(absCtx, 1);
+          int rateHi = 0, rateLo = 0;                          /* xGetICRate(maxAbsLevel), (maxAbsLevel - 1) from the level choice */
           if (scanPos == lastScanPos)
             level = coded_level(cb, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                                sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1);
+                                sigOff, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1, &rateHi, &rateLo);
           else {
             level = coded_level(cb, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
-                                ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0);
+                                ctxSig, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0, &rateHi, &rateLo);
             sdel = sbit1 - sbit0;
           }
-          if (level > 0) {
-            const int rateNow = ic_rate(lb, level, goRice, c1Idx, c2Idx);
-            rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateNow;
-            rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateNow;
+          if (level > 0) {                                     /* the chosen level is maxAbsLevel or maxAbsLevel - 1: one new rate, not three */
+            if (level == maxAbsLevel) {
+              rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateHi;
+              rdn = (maxAbsLevel > 1 ? rateLo : ic_rate(lb, 0, goRice, c1Idx, c2Idx)) - rateHi;
+            } else {
+              rup = rateHi - rateLo;
+              rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateLo;
+            }
           } else rup = lb.g10;
         }
         RdoqRec r; r.cc = cc; r.cs = cs; r.c0 = c0; r.up = rup; r.dn = rdn; r.sd = sdel;
