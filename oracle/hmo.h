@@ -162,6 +162,13 @@ void    hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, cons
                        uint8_t *recY, uint8_t *recU, uint8_t *recV);
 /* P slice: the reference picture (list 0, index 0), i.e. the previous picture after the loop filters */
 void    hmo_set_ref_planes(HmoEnc *e, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV);
+/* several reference pictures (RefPicList0[idx], idx < HMO_MAX_REF): planes + POC of each, and the current picture's POC.
+ * hmo_set_ref_planes alone = one reference at POC distance 1. */
+#define HMO_MAX_REF 4
+void    hmo_set_ref_picture(HmoEnc *e, int idx, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV, int poc);
+void    hmo_set_poc(HmoEnc *e, int poc, int n_ref);
+/* TMVP with several references: POC of the collocated picture and the POCs its own reference list named (by refIdx) */
+void    hmo_set_col_pocs(HmoEnc *e, int col_poc, const int *col_ref_poc, int n);
 /* compressCtu + encodeCtu replay for CTU ctuRsAddr (must be called in raster order). */
 void    hmo_compress_ctu(HmoEnc *e, int ctuRsAddr);
 const HmoCtu *hmo_get_ctu(const HmoEnc *e, int ctuRsAddr);

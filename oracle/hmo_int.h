@@ -67,6 +67,12 @@ struct HmoEnc {
   const uint8_t *org[3];
   uint8_t *rec[3];
   const uint8_t *ref[3];             /* P slice: reference picture (list 0, index 0) = previous picture after the loop filters */
+  /* reference picture list 0 (P slices): refs[r] = planes of RefPicList0[r] (refs[0] == ref), ref_poc[r] its POC, poc the
+   * current picture's; n_ref = num_ref_idx_l0_active (1..4).  With one reference and consecutive pictures no vector is ever
+   * scaled; with several, AMVP / TMVP scale by POC distance (xGetDistScaleFactor, TComDataCU.cpp:3312). */
+  const uint8_t *refs[HMO_MAX_REF][3];
+  int n_ref, poc, ref_poc[HMO_MAX_REF];
+  int col_poc, col_ref_poc[HMO_MAX_REF];      /* collocated picture (= RefPicList0[0]): its POC and the POCs its own list 0 named */
   int stride[3];
   HmoCtu *pic;                       /* per-CTU committed decisions (TComPic CTU objects) */
   uint32_t *replay_bits;
@@ -108,7 +114,7 @@ struct HmoEnc {
    * search code (oracle/ref/make_golden_search.py) or compare with what it returned (tests/test_golden_search.py) */
   void (*trace)(void *user, int event, int depth, int arg);
   void *trace_user;
-  struct { int x, y; } int_mv_2nx2n;           /* m_integerMv2Nx2N[list 0][ref 0]: integer vector of the last 2Nx2N motion search (TZ search start point) */
+  struct { int x, y; } int_mv_2nx2n[HMO_MAX_REF];   /* m_integerMv2Nx2N[list 0][ref]: integer vector of the last 2Nx2N motion search on that reference (TZ search start point) */
   const HmoCtu *col;            /* motion field of the collocated picture (TMVP) */
   HmoPuTrace *pu_trace;         /* optional per-PU record of the luma search (hmo_set_pu_trace) */
 };

@@ -84,24 +84,44 @@ static int same_motion(const HmoNb *a, const HmoNb *b) { return a->mv.x == b->mv
  * collocated_ref_idx 0).  xGetColMVP, TComDataCU.cpp:3175-3242: the motion the collocated picture holds at a position after
  * TComPic::compressMotion (the top-left 4x4 partition of every 16x16 block stands for the block); not available where that
  * partition is intra.  With consecutive pictures and one reference both POC distances are 1: no scaling (iScale == 4096). */
-static int col_mvp(const HmoEnc *e, int x, int y, HmoMv *mv)
+/* xGetDistScaleFactor, TComDataCU.cpp:3312-3329, and TComMv::scaleMv, TComMv.h:145-150 */
+static int dist_scale(int curPoc, int curRefPoc, int colPoc, int colRefPoc)
+{
+  const int dD = colPoc - colRefPoc, dB = curPoc - curRefPoc;
+  if (dD == dB) return 4096;
+  const int tdb = dB < -128 ? -128 : (dB > 127 ? 127 : dB), tdd = dD < -128 ? -128 : (dD > 127 ? 127 : dD);
+  const int x = (0x4000 + abs(tdd / 2)) / tdd;
+  const int sc = (tdb * x + 32) >> 6;
+  return sc < -4096 ? -4096 : (sc > 4095 ? 4095 : sc);
+}
+static HmoMv scale_mv(HmoMv m, int sc)
+{
+  if (sc == 4096) return m;
+  int vx = (sc * m.x + 127 + (sc * m.x < 0)) >> 8, vy = (sc * m.y + 127 + (sc * m.y < 0)) >> 8;
+  HmoMv r; r.x = vx < -32768 ? -32768 : (vx > 32767 ? 32767 : vx); r.y = vy < -32768 ? -32768 : (vy > 32767 ? 32767 : vy);
+  return r;
+}
+/* the collocated vector for a PU that references RefPicList0[refIdx]: scaled by the ratio of the two POC distances */
+static int col_mvp(const HmoEnc *e, int x, int y, int refIdx, HmoMv *mv)
 {
   if (!e->col) return 0;
   const int xc = x & ~15, yc = y & ~15;
   const HmoCtu *c = &e->col[(yc >> 6) * e->w_ctu + (xc >> 6)];
   const int z = zidx_of(xc & 63, yc & 63);
   if (c->pred_mode[z] != HMO_MODE_INTER || c->ref_idx[z] < 0) return 0;
-  mv->x = c->mv[z][0]; mv->y = c->mv[z][1];
+  HmoMv m; m.x = c->mv[z][0]; m.y = c->mv[z][1];
+  const int cr = c->ref_idx[z] < HMO_MAX_REF ? c->ref_idx[z] : 0;
+  *mv = scale_mv(m, dist_scale(e->poc, e->ref_poc[refIdx], e->col_poc, e->col_ref_poc[cr]));
   return 1;
 }
 /* the temporal candidate of a PU: bottom-right neighbour (H) when it lies inside the picture and in the same CTU row
  * (TComDataCU.cpp:2528-2563 / :2863-2900), else the centre of the PU (xDeriveCenterIdx) */
-static int temporal_candidate(const HmoEnc *e, int xP, int yP, int w, int h, HmoMv *mv)
+static int temporal_candidate(const HmoEnc *e, int xP, int yP, int w, int h, int refIdx, HmoMv *mv)
 {
   if (!e->p.tmvp) return 0;
   const int bx = xP + w, by = yP + h;
-  if (bx < e->p.width && by < e->p.height && (by & 63) != 0 && col_mvp(e, bx, by, mv)) return 1;
-  return col_mvp(e, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), mv);
+  if (bx < e->p.width && by < e->p.height && (by & 63) != 0 && col_mvp(e, bx, by, refIdx, mv)) return 1;
+  return col_mvp(e, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), refIdx, mv);
 }
 
 static int merge_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int pu, HmoMv mv[5], int ref[5])
@@ -132,36 +152,48 @@ static int merge_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int 
     if (okB2 && (!okA1 || !same_motion(&a1, &b2)) && (!okB1 || !same_motion(&b1, &b2))) { mv[n] = b2.mv; ref[n] = b2.ref; n++; }
   }
   if (n == maxc) return n;
-  { HmoMv t; if (temporal_candidate(e, xP, yP, w, h, &t)) { mv[n] = t; ref[n] = 0; n++; } }
+  { HmoMv t; if (temporal_candidate(e, xP, yP, w, h, 0, &t)) { mv[n] = t; ref[n] = 0; n++; } }   /* the temporal merge candidate references index 0 (:2566) */
   if (n == maxc) return n;
-  while (n < maxc) { mv[n].x = mv[n].y = 0; ref[n] = 0; n++; }                /* zero candidates: one reference picture -> r stays 0 */
+  for (int r = 0, refcnt = 0; n < maxc; n++) {                  /* zero candidates walk the reference indices (:2672-2686) */
+    mv[n].x = mv[n].y = 0; ref[n] = r;
+    if (refcnt == e->n_ref - 1) r = 0; else { ++r; ++refcnt; }
+  }
   return n;
 }
 
-/* fillMvpCand for one reference picture, no TMVP: left (A0 else A1), above (B0 else B1 else B2), equal pair pruned,
- * padded with zero vectors to AMVP_MAX_NUM_CANDS = 2.  (With a single reference POC the scaled "Order" variants add
- * nothing the plain ones did not: they repeat the first inter above neighbour, which the equality pruning removes.) */
-static void amvp_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int pu, HmoMv cand[2])
+/* fillMvpCand (TComDataCU.cpp:2781-2925) for RefPicList0[refIdx]: the left pair (A0, A1) and the above triple (B0, B1, B2),
+ * each first for a neighbour that references the same picture (xAddMVPCand, :3005-3074), then -- left: if that found nothing;
+ * above: only if no left neighbour was inter -- for any inter neighbour with its vector scaled by the ratio of the POC
+ * distances (xAddMVPCandOrder, :3084-3215); equal pair pruned, temporal candidate appended, cut / padded to two. */
+static int mvp_same(const HmoEnc *e, const HmoNb *nb, int refIdx, HmoMv *cand, int *n)
+{ if (nb->avail && nb->ref >= 0 && e->ref_poc[nb->ref] == e->ref_poc[refIdx]) { cand[(*n)++] = nb->mv; return 1; } return 0; }
+static int mvp_scaled(const HmoEnc *e, const HmoNb *nb, int refIdx, HmoMv *cand, int *n)
+{ if (nb->avail && nb->ref >= 0) { cand[(*n)++] = scale_mv(nb->mv, dist_scale(e->poc, e->ref_poc[refIdx], e->poc, e->ref_poc[nb->ref])); return 1; } return 0; }
+static void amvp_candidates(const HmoEnc *e, const HmoCU *cu, int partSize, int pu, int refIdx, HmoMv cand[2])
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
   const int xP = cu->x + ox, yP = cu->y + oy;
   const int lbx = xP, lby = yP + h - 1, rtx = xP + w - 1, rty = yP;
-  int n = 0;
+  int n = 0; HmoMv c3[4];
   HmoNb a0 = nb_motion(e, cu, xP - 1, yP + h, lbx, lby), a1 = nb_motion(e, cu, xP - 1, yP + h - 1, lbx, lby);
   const int addedSmvp = (a0.avail && a0.inter) || (a1.avail && a1.inter);
-  if (a0.avail && a0.ref >= 0) cand[n++] = a0.mv;
-  else if (a1.avail && a1.ref >= 0) cand[n++] = a1.mv;
+  int added = mvp_same(e, &a0, refIdx, c3, &n);
+  if (!added) added = mvp_same(e, &a1, refIdx, c3, &n);
+  if (!added) { added = mvp_scaled(e, &a0, refIdx, c3, &n); if (!added) mvp_scaled(e, &a1, refIdx, c3, &n); }
   HmoNb b0 = nb_motion(e, cu, xP + w, yP - 1, rtx, rty), b1 = nb_motion(e, cu, xP + w - 1, yP - 1, rtx, rty), b2 = nb_motion(e, cu, xP - 1, yP - 1, xP, yP);
-  HmoMv above; int haveAbove = 1;
-  if (b0.avail && b0.ref >= 0) above = b0.mv;
-  else if (b1.avail && b1.ref >= 0) above = b1.mv;
-  else if (b2.avail && b2.ref >= 0) above = b2.mv;
-  else haveAbove = 0;
-  if (haveAbove) cand[n++] = above;
-  if (!addedSmvp && haveAbove && n < 2) cand[n++] = above;      /* xAddMVPCandOrder repeats the first inter above neighbour (:2852-2864) */
-  if (n == 2 && cand[0].x == cand[1].x && cand[0].y == cand[1].y) n = 1;
-  { HmoMv t; if (n < 2 && temporal_candidate(e, xP, yP, w, h, &t)) cand[n++] = t; }    /* appended, then the list is cut to two (:2863-2925) */
-  while (n < 2) { cand[n].x = cand[n].y = 0; n++; }
+  added = mvp_same(e, &b0, refIdx, c3, &n);
+  if (!added) added = mvp_same(e, &b1, refIdx, c3, &n);
+  if (!added) mvp_same(e, &b2, refIdx, c3, &n);
+  if (!addedSmvp) {
+    added = mvp_scaled(e, &b0, refIdx, c3, &n);
+    if (!added) added = mvp_scaled(e, &b1, refIdx, c3, &n);
+    if (!added) mvp_scaled(e, &b2, refIdx, c3, &n);
+  }
+  if (n == 2 && c3[0].x == c3[1].x && c3[0].y == c3[1].y) n = 1;
+  { HmoMv t; if (n < 3 && temporal_candidate(e, xP, yP, w, h, refIdx, &t)) c3[n++] = t; }
+  if (n > 2) n = 2;
+  while (n < 2) { c3[n].x = c3[n].y = 0; n++; }
+  cand[0] = c3[0]; cand[1] = c3[1];
 }
 
 /* clipMv, TComDataCU.cpp:2930-2942 (offsets relative to the CU's position) */
@@ -182,14 +214,14 @@ static HmoMv clip_mv(const HmoEnc *e, const HmoCU *cu, HmoMv mv)
  * ---------------------------------------------------------------------------------- */
 static const int8_t k_luma_filter[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
 static const int8_t k_chroma_filter[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
-static inline int ref_sample(const HmoEnc *e, int comp, int x, int y)
+static inline int ref_sample(const HmoEnc *e, int r, int comp, int x, int y)
 {
   const int w = comp ? e->p.width >> 1 : e->p.width, h = comp ? e->p.height >> 1 : e->p.height;
   x = x < 0 ? 0 : (x >= w ? w - 1 : x); y = y < 0 ? 0 : (y >= h ? h - 1 : y);
-  return e->ref[comp][y * e->stride[comp] + x];
+  return e->refs[r][comp][y * e->stride[comp] + x];
 }
 /* block of size w x h (component samples) whose top-left is at (bx, by) displaced by mv (luma: quarter, chroma: eighth units) */
-static void mc_block(const HmoEnc *e, int comp, int bx, int by, int w, int h, int mvx, int mvy, uint8_t *dst, int ds)
+static void mc_block(const HmoEnc *e, int r, int comp, int bx, int by, int w, int h, int mvx, int mvy, uint8_t *dst, int ds)
 {
   const int sh = comp ? 3 : 2, taps = comp ? 4 : 8, half = taps / 2 - 1;
   const int ix = bx + (mvx >> sh), iy = by + (mvy >> sh), fx = mvx & ((1 << sh) - 1), fy = mvy & ((1 << sh) - 1);
@@ -198,7 +230,7 @@ static void mc_block(const HmoEnc *e, int comp, int bx, int by, int w, int h, in
   for (int y = 0; y < h + taps - 1; y++)
     for (int x = 0; x < w; x++) {
       int s = 0;
-      for (int t = 0; t < taps; t++) s += ch[t] * ref_sample(e, comp, ix + x + t - half, iy + y - half);
+      for (int t = 0; t < taps; t++) s += ch[t] * ref_sample(e, r, comp, ix + x + t - half, iy + y - half);
       tmp[y * w + x] = s;
     }
   for (int y = 0; y < h; y++)
@@ -214,10 +246,11 @@ static void mc_pu(const HmoEnc *e, const HmoCU *cu, int partSize, int pu, HmoYuv
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
   HmoMv mv; mv.x = cu->mv[addr][0]; mv.y = cu->mv[addr][1];
+  const int r = cu->ref_idx[addr] > 0 ? cu->ref_idx[addr] : 0;
   mv = clip_mv(e, cu, mv);
-  mc_block(e, 0, cu->x + ox, cu->y + oy, w, h, mv.x, mv.y, dst->y + oy * 64 + ox, 64);
-  mc_block(e, 1, (cu->x + ox) >> 1, (cu->y + oy) >> 1, w >> 1, h >> 1, mv.x, mv.y, dst->u + (oy >> 1) * 32 + (ox >> 1), 32);
-  mc_block(e, 2, (cu->x + ox) >> 1, (cu->y + oy) >> 1, w >> 1, h >> 1, mv.x, mv.y, dst->v + (oy >> 1) * 32 + (ox >> 1), 32);
+  mc_block(e, r, 0, cu->x + ox, cu->y + oy, w, h, mv.x, mv.y, dst->y + oy * 64 + ox, 64);
+  mc_block(e, r, 1, (cu->x + ox) >> 1, (cu->y + oy) >> 1, w >> 1, h >> 1, mv.x, mv.y, dst->u + (oy >> 1) * 32 + (ox >> 1), 32);
+  mc_block(e, r, 2, (cu->x + ox) >> 1, (cu->y + oy) >> 1, w >> 1, h >> 1, mv.x, mv.y, dst->v + (oy >> 1) * 32 + (ox >> 1), 32);
 }
 
 /* ------------------------------------------------------------------------------------
@@ -233,13 +266,13 @@ static uint32_t mv_bits(int x, int y, HmoMv pred, int scale) { return mv_comp_bi
 static uint32_t motion_cost(const HmoEnc *e, uint32_t bits) { return (e->p.lambda_motion_sad * bits) >> 16; }       /* getCost(b) with m_uiCost = m_uiLambdaMotionSAD */
 
 /* xGetSAD* with iSubShift: rows 0, step, 2*step, ...; sum << shift */
-static uint32_t sad_ref(const HmoEnc *e, const uint8_t *org, int so, int rx, int ry, int w, int h, int subShift)
+static uint32_t sad_ref(const HmoEnc *e, int ri, const uint8_t *org, int so, int rx, int ry, int w, int h, int subShift)
 {
   uint32_t s = 0; const int step = 1 << subShift;
   if (rx >= 0 && ry >= 0 && rx + w <= e->p.width && ry + h <= e->p.height) {
-    for (int y = 0; y < h; y += step) { const uint8_t *r = e->ref[0] + (ry + y) * e->stride[0] + rx, *o = org + y * so; for (int x = 0; x < w; x++) s += (uint32_t)abs(o[x] - r[x]); }
+    for (int y = 0; y < h; y += step) { const uint8_t *r = e->refs[ri][0] + (ry + y) * e->stride[0] + rx, *o = org + y * so; for (int x = 0; x < w; x++) s += (uint32_t)abs(o[x] - r[x]); }
   } else {
-    for (int y = 0; y < h; y += step) for (int x = 0; x < w; x++) s += (uint32_t)abs(org[y * so + x] - ref_sample(e, 0, rx + x, ry + y));
+    for (int y = 0; y < h; y += step) for (int x = 0; x < w; x++) s += (uint32_t)abs(org[y * so + x] - ref_sample(e, ri, 0, rx + x, ry + y));
   }
   return s << subShift;
 }
@@ -249,16 +282,16 @@ static uint32_t sad_blocks(const uint8_t *a, int sa, const uint8_t *b, int sb, i
 /* ------------------------------------------------------------------------------------
  * xEstimateMvPredAMVP + xGetTemplateCost
  * ---------------------------------------------------------------------------------- */
-static HmoMv estimate_mvp(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv cand[2], int *bestIdx)
+static HmoMv estimate_mvp(HmoEnc *e, HmoCU *cu, int partSize, int pu, int refIdx, HmoMv cand[2], int *bestIdx)
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
-  amvp_candidates(e, cu, partSize, pu, cand);
+  amvp_candidates(e, cu, partSize, pu, refIdx, cand);
   const uint8_t *org = e->org_yuv[cu->depth_cu]->y + oy * 64 + ox;
   uint32_t best = HMO_MAX_UINT; int bi = 0;
   for (int i = 0; i < 2; i++) {                                 /* pInfo->iN is always 2 after the zero padding */
     HmoMv c = clip_mv(e, cu, cand[i]);
     uint8_t blk[64 * 64];
-    mc_block(e, 0, cu->x + ox, cu->y + oy, w, h, c.x, c.y, blk, 64);
+    mc_block(e, refIdx, 0, cu->x + ox, cu->y + oy, w, h, c.x, c.y, blk, 64);
     const uint32_t sad = sad_blocks(blk, 64, org, 64, w, h);
     /* calcRdCost(bits = m_auiMVPIdxCost[i][2] = 1, dist, false, DF_SAD), TComRdCost.cpp:100-103 */
     const uint32_t cost = (uint32_t)floor((double)sad + (floor(((double)1 * (double)e->p.lambda_motion_sad) + 0.5) / 65536.0));
@@ -277,11 +310,11 @@ static const int8_t k_refine_q[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1
 /* ---- xTZSearch (FastSearch 1), TEncSearch.cpp:3981-4180, with TZ_SEARCH_CONFIGURATION (:301-317): zero-vector test on,
  * other predictors off, diamond first search that stops three rounds after the last improvement (FASTME_SMOOTHER_MV),
  * raster search with step 5 when the best distance is larger, star refinement with diamonds, no raster refinement. */
-typedef struct { uint32_t best; int bx, by, dist, round, point; const uint8_t *org; int px, py, w, h, sub; HmoMv pred; } HmoTz;
+typedef struct { uint32_t best; int bx, by, dist, round, point; const uint8_t *org; int px, py, w, h, sub, ref; HmoMv pred; } HmoTz;
 /* xTZSearchHelp, :336-441 (not the selective variant) */
 static void tz_help(HmoEnc *e, HmoTz *s, int x, int y, int point, int dist)
 {
-  uint32_t sad = sad_ref(e, s->org, 64, s->px + x, s->py + y, s->w, s->h, s->sub) + motion_cost(e, mv_bits(x, y, s->pred, 2));
+  uint32_t sad = sad_ref(e, s->ref, s->org, 64, s->px + x, s->py + y, s->w, s->h, s->sub) + motion_cost(e, mv_bits(x, y, s->pred, 2));
   e->n_sad++;
   if (sad < s->best) { s->best = sad; s->bx = x; s->by = y; s->dist = dist; s->round = 0; s->point = point; }
 }
@@ -387,7 +420,7 @@ static void tz_search(HmoEnc *e, const HmoCU *cu, HmoTz *s, HmoMv lt, HmoMv rb, 
   *outX = s->bx; *outY = s->by;
 }
 
-static void motion_estimation(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv pred, HmoMv *mvOut, uint32_t *bits, uint32_t *cost)
+static void motion_estimation(HmoEnc *e, HmoCU *cu, int partSize, int pu, int refIdx, HmoMv pred, HmoMv *mvOut, uint32_t *bits, uint32_t *cost)
 {
   int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
   const uint8_t *org = e->org_yuv[cu->depth_cu]->y + oy * 64 + ox;
@@ -400,24 +433,24 @@ static void motion_estimation(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv 
     uint32_t best = HMO_MAX_UINT;
     for (int y = lt.y; y <= rb.y; y++)
       for (int x = lt.x; x <= rb.x; x++) {
-        uint32_t s = sad_ref(e, org, 64, px + x, py + y, w, h, subShift);
+        uint32_t s = sad_ref(e, refIdx, org, 64, px + x, py + y, w, h, subShift);
         s += motion_cost(e, mv_bits(x, y, pred, 2));
         if (s < best) { best = s; bx = x; by = y; }
       }
     e->n_sad += (uint64_t)(rb.y - lt.y + 1) * (uint64_t)(rb.x - lt.x + 1);
   } else {                                                   /* xPatternSearchFast -> xTZSearch; m_integerMv2Nx2N, TEncSearch.cpp:3822-3833 */
-    HmoTz s; s.org = org; s.px = px; s.py = py; s.w = w; s.h = h; s.sub = subShift; s.pred = pred;
+    HmoTz s; s.org = org; s.px = px; s.py = py; s.w = w; s.h = h; s.sub = subShift; s.pred = pred; s.ref = refIdx;
     const int usePred = partSize != HMO_SIZE_2Nx2N || cu->depth_cu != 0;
-    HmoMv imv; imv.x = e->int_mv_2nx2n.x; imv.y = e->int_mv_2nx2n.y;
+    HmoMv imv; imv.x = e->int_mv_2nx2n[refIdx].x; imv.y = e->int_mv_2nx2n[refIdx].y;
     tz_search(e, cu, &s, lt, rb, usePred ? &imv : NULL, &bx, &by);
-    if (partSize == HMO_SIZE_2Nx2N) { e->int_mv_2nx2n.x = bx; e->int_mv_2nx2n.y = by; }
+    if (partSize == HMO_SIZE_2Nx2N) { e->int_mv_2nx2n[refIdx].x = bx; e->int_mv_2nx2n[refIdx].y = by; }
   }
   /* xPatternSearchFracDIF: half positions around (bx, by), cost scale 1; then quarter positions, cost scale 0 */
   uint8_t blk[64 * 64];
   uint32_t bestD = HMO_MAX_UINT; int bh = 0;
   for (int i = 0; i < 9; i++) {
     const int hx = k_refine_h[i][0], hy = k_refine_h[i][1];
-    mc_block(e, 0, px, py, w, h, (bx << 2) + 2 * hx, (by << 2) + 2 * hy, blk, 64);
+    mc_block(e, refIdx, 0, px, py, w, h, (bx << 2) + 2 * hx, (by << 2) + 2 * hy, blk, 64);
     uint32_t d = e->p.had_me ? hmo_satd(org, 64, blk, 64, w, h) : sad_blocks(org, 64, blk, 64, w, h);
     d += motion_cost(e, mv_bits((bx << 1) + hx, (by << 1) + hy, pred, 1));
     if (d < bestD) { bestD = d; bh = i; }
@@ -427,7 +460,7 @@ static void motion_estimation(HmoEnc *e, HmoCU *cu, int partSize, int pu, HmoMv 
   for (int i = 0; i < 9; i++) {
     const int qx = k_refine_q[i][0], qy = k_refine_q[i][1];
     const int mx = (bx << 2) + 2 * hx + qx, my = (by << 2) + 2 * hy + qy;
-    mc_block(e, 0, px, py, w, h, mx, my, blk, 64);
+    mc_block(e, refIdx, 0, px, py, w, h, mx, my, blk, 64);
     uint32_t d = e->p.had_me ? hmo_satd(org, 64, blk, 64, w, h) : sad_blocks(org, 64, blk, 64, w, h);
     d += motion_cost(e, mv_bits(mx, my, pred, 0));
     if (d < bestD) { bestD = d; bq = i; }
@@ -475,18 +508,25 @@ static void pred_inter_search(HmoEnc *e, HmoCU *cu, int partSize, int useMrg)
   for (int pu = 0; pu < npu; pu++) {
     int addr, ox, oy, w, h; pu_geom(cu, partSize, pu, &addr, &ox, &oy, &w, &h);
     const uint32_t mbBits = (partSize == HMO_SIZE_2Nx2N || partSize == HMO_SIZE_NxN) ? 1 : 3;   /* xGetBlkBits, P slice */
-    HmoMv cand[2], pred, mv; int mvpIdx;
+    HmoMv pred, mv; int mvpIdx, refBest = 0;
     uint32_t bitsT = mbBits, costT = 0;
     HmoMv zero = { 0, 0 };
     mv = zero; pred = zero; mvpIdx = -1;
     if (normalMC) {
-      pred = estimate_mvp(e, cu, partSize, pu, cand, &mvpIdx);
-      bitsT += 1;                                              /* m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS] */
-      motion_estimation(e, cu, partSize, pu, pred, &mv, &bitsT, &costT);
-      check_best_mvp(e, mv, cand, &pred, &mvpIdx, &bitsT, &costT);
+      uint32_t costBest = HMO_MAX_UINT;
+      for (int r = 0; r < e->n_ref; r++) {                      /* uni-directional prediction, list 0: every reference index (:3110-3190) */
+        HmoMv candR[2], predR, mvR; int idxR;
+        uint32_t bitsR = mbBits, costR = 0;
+        if (e->n_ref > 1) { bitsR += (uint32_t)r + 1; if (r == e->n_ref - 1) bitsR--; }      /* ref_idx bins (:3114-3121) */
+        predR = estimate_mvp(e, cu, partSize, pu, r, candR, &idxR);
+        bitsR += 1;                                            /* m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS] */
+        motion_estimation(e, cu, partSize, pu, r, predR, &mvR, &bitsR, &costR);
+        check_best_mvp(e, mvR, candR, &predR, &idxR, &bitsR, &costR);
+        if (costR < costBest) { costBest = costR; bitsT = bitsR; costT = costR; mv = mvR; pred = predR; mvpIdx = idxR; refBest = r; }
+      }
       /* motion field of the PU: list 0 wins by construction (:3413-3427) */
       HmoMv mvd; mvd.x = mv.x - pred.x; mvd.y = mv.y - pred.y;
-      pu_set_motion(cu, partSize, pu, mv, 0); pu_set_mvd(cu, partSize, pu, mvd); pu_set_dir(cu, partSize, pu, 1); pu_set_mvp(cu, partSize, pu, mvpIdx);
+      pu_set_motion(cu, partSize, pu, mv, refBest); pu_set_mvd(cu, partSize, pu, mvd); pu_set_dir(cu, partSize, pu, 1); pu_set_mvp(cu, partSize, pu, mvpIdx);
     } else {                                                   /* the cleared motion field (:3356-3363) */
       pu_set_motion(cu, partSize, pu, zero, -1); pu_set_mvd(cu, partSize, pu, zero); pu_set_mvp(cu, partSize, pu, -1);
     }
@@ -507,7 +547,7 @@ static void pred_inter_search(HmoEnc *e, HmoCU *cu, int partSize, int useMrg)
         pu_set_merge(cu, partSize, pu, 1, mrgIdx); pu_set_dir(cu, partSize, pu, 1);
         pu_set_motion(cu, partSize, pu, mmv[mrgIdx], mref[mrgIdx]); pu_set_mvd(cu, partSize, pu, zero); pu_set_mvp(cu, partSize, pu, -1);
       } else {
-        pu_set_merge(cu, partSize, pu, 0, 0); pu_set_dir(cu, partSize, pu, 1); pu_set_motion(cu, partSize, pu, mv, 0);
+        pu_set_merge(cu, partSize, pu, 0, 0); pu_set_dir(cu, partSize, pu, 1); pu_set_motion(cu, partSize, pu, mv, refBest);
       }
     }
     mc_pu(e, cu, partSize, pu, e->pred_temp[d]);
@@ -558,7 +598,20 @@ static void code_mvd(HmoEnc *e, int hor, int ver)
   if (hor) { if (ah > 1) hmo_enc_bins_ep(e, ep_exgolomb_bins(ah - 2, 1)); hmo_enc_bins_ep(e, 1); }
   if (ver) { if (av > 1) hmo_enc_bins_ep(e, ep_exgolomb_bins(av - 2, 1)); hmo_enc_bins_ep(e, 1); }
 }
-/* encodePUWise, TEncEntropy.cpp:456-507 (one reference picture: no ref_idx; P slice: no inter_pred_idc) */
+/* codeRefFrmIdx, TEncSbac.cpp:743-775: first bin on context 0, second on context 1, the rest bypass (truncated unary) */
+static void code_ref_idx(HmoEnc *e, int refIdx)
+{
+  hmo_enc_bin(e, refIdx == 0 ? 0 : 1, HMO_CTX_REF);
+  if (refIdx > 0) {
+    const int refNum = e->n_ref - 2; refIdx--;
+    for (int ui = 0; ui < refNum; ui++) {
+      const int sym = ui == refIdx ? 0 : 1;
+      if (ui == 0) hmo_enc_bin(e, sym, HMO_CTX_REF + 1); else hmo_enc_bins_ep(e, 1);
+      if (!sym) break;
+    }
+  }
+}
+/* encodePUWise, TEncEntropy.cpp:456-507 (P slice: no inter_pred_idc; ref_idx only with several reference pictures) */
 static void code_pu_wise(HmoEnc *e, const HmoCU *cu, int part)
 {
   const int ps = cu->part_size[part], npu = pu_count(ps), n = HMO_NPART >> (2 * cu->depth[part]);
@@ -567,7 +620,7 @@ static void code_pu_wise(HmoEnc *e, const HmoCU *cu, int part)
   for (int pu = 0, sp = part; pu < npu; pu++, sp += off) {
     hmo_enc_bin(e, cu->merge_flag[sp], HMO_CTX_MERGE_FLAG);
     if (cu->merge_flag[sp]) code_merge_index(e, cu, sp);
-    else { code_mvd(e, cu->mvd[sp][0], cu->mvd[sp][1]); hmo_enc_bin(e, cu->mvp_idx[sp], HMO_CTX_MVP_IDX); }
+    else { if (e->n_ref > 1) code_ref_idx(e, cu->ref_idx[sp]); code_mvd(e, cu->mvd[sp][0], cu->mvd[sp][1]); hmo_enc_bin(e, cu->mvp_idx[sp], HMO_CTX_MVP_IDX); }
   }
 }
 static int qt_root_cbf(const HmoCU *cu, int part) { return ((cu->cbf[0][part] | cu->cbf[1][part] | cu->cbf[2][part]) & 1); }

@@ -117,10 +117,15 @@ PUS_PER_CTU = 341
 class Encoder:
     """One chain: a frame (or its slices) decided CTU by CTU in raster order."""
 
-    def __init__(self, Y, U, V, qp, slice_ctus=0, ref=None, col=None, **flags):
+    def __init__(self, Y, U, V, qp, slice_ctus=0, ref=None, col=None, refs=None, ref_pocs=None, poc=None, col_ref_pocs=None, **flags):
         """ref = (Y, U, V) planes of the reference picture makes this a P picture (slice_type P, list 0, index 0);
         col = the reference picture's decided CTUs (bytes of its Ctu array: all_ctus_bytes()) switches TMVP on;
+        refs = [(Y, U, V), ...] (up to 4) with ref_pocs = their POCs and poc = this picture's: several reference pictures
+        (RefPicList0 in that order; refs[0] is also the collocated picture, col_ref_pocs = the POCs ITS list 0 named);
         flags: any Params field (search_range, fast_enc, lambda_override, ...)."""
+        if refs is not None:
+            assert ref is None and 1 <= len(refs) <= 4 and len(ref_pocs) == len(refs) and poc is not None
+            ref = refs[0]
         self.lib = load()
         h, w = Y.shape
         self.p = Params()
@@ -145,6 +150,17 @@ class Encoder:
         if ref is not None:
             self.ref = [np.ascontiguousarray(a, dtype=np.uint8) for a in ref]
             self.lib.hmo_set_ref_planes(self.h, *[a.ctypes.data for a in self.ref])
+        self.refs = None
+        if refs is not None:
+            self.refs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in r] for r in refs]
+            self.lib.hmo_set_ref_picture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            for i, r in enumerate(self.refs):
+                self.lib.hmo_set_ref_picture(self.h, i, *[a.ctypes.data for a in r], int(ref_pocs[i]))
+            self.lib.hmo_set_poc.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            self.lib.hmo_set_poc(self.h, int(poc), len(refs))
+            crp = np.ascontiguousarray(col_ref_pocs if col_ref_pocs is not None else [ref_pocs[0] - 1], np.int32)
+            self.lib.hmo_set_col_pocs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            self.lib.hmo_set_col_pocs(self.h, int(ref_pocs[0]), crp.ctypes.data, len(crp))
         self.col = None
         if col is not None:
             assert len(col) == C.sizeof(Ctu) * self.n_ctu
@@ -219,10 +235,10 @@ class Encoder:
         return v
 
     def test_int_mv(self):
-        xy = (C.c_int * 2)()
+        xy = (C.c_int * 8)()
         self.lib.hmo_test_int_mv.argtypes = [C.c_void_p, C.c_void_p]
         self.lib.hmo_test_int_mv(self.h, xy)
-        return int(xy[0]), int(xy[1])
+        return [(int(xy[2 * r]), int(xy[2 * r + 1])) for r in range(4)]       # per reference index
 
     def enable_pu_trace(self):
         """per-PU record of the luma search (BASELINE configs[1]): structured array [n_ctu, 341], filled as CTUs are decided"""

@@ -1026,7 +1026,12 @@ void hmo_set_planes(HmoEnc *e, const uint8_t *orgY, const uint8_t *orgU, const u
   e->stride[0] = e->p.width; e->stride[1] = e->stride[2] = e->p.width / 2;
 }
 /* reference picture of a P slice (list 0, index 0): planes of the picture size, same strides as the reconstruction */
-void hmo_set_ref_planes(HmoEnc *e, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV) { e->ref[0] = refY; e->ref[1] = refU; e->ref[2] = refV; }
+void hmo_set_ref_planes(HmoEnc *e, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV)
+{ e->ref[0] = refY; e->ref[1] = refU; e->ref[2] = refV; e->refs[0][0] = refY; e->refs[0][1] = refU; e->refs[0][2] = refV; e->n_ref = 1; e->poc = 1; e->ref_poc[0] = 0; e->col_poc = 0; e->col_ref_poc[0] = -1; }
+void hmo_set_ref_picture(HmoEnc *e, int idx, const uint8_t *refY, const uint8_t *refU, const uint8_t *refV, int poc)
+{ if (idx < 0 || idx >= HMO_MAX_REF) return; e->refs[idx][0] = refY; e->refs[idx][1] = refU; e->refs[idx][2] = refV; e->ref_poc[idx] = poc; if (idx == 0) { e->ref[0] = refY; e->ref[1] = refU; e->ref[2] = refV; } }
+void hmo_set_poc(HmoEnc *e, int poc, int n_ref) { e->poc = poc; e->n_ref = n_ref < 1 ? 1 : (n_ref > HMO_MAX_REF ? HMO_MAX_REF : n_ref); }
+void hmo_set_col_pocs(HmoEnc *e, int col_poc, const int *col_ref_poc, int n) { e->col_poc = col_poc; for (int i = 0; i < HMO_MAX_REF; i++) e->col_ref_poc[i] = i < n ? col_ref_poc[i] : col_poc - 1; }
 uint64_t hmo_test_n_sad(const HmoEnc *e) { return e->n_sad; }
 int hmo_num_ctus(const HmoEnc *e) { return e->n_ctu; }
 /* fork state of the frame (getCurrentState, tools_YS.cpp:1237-1242), the per-depth decision switches of the Naive model
@@ -1057,7 +1062,7 @@ const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
 void hmo_set_col(HmoEnc *e, const HmoCtu *col) { e->col = col; }
 void hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf) { e->pu_trace = buf; }
-void hmo_test_int_mv(const HmoEnc *e, int *xy) { xy[0] = e->int_mv_2nx2n.x; xy[1] = e->int_mv_2nx2n.y; }
+void hmo_test_int_mv(const HmoEnc *e, int *xy) { for (int r = 0; r < HMO_MAX_REF; r++) { xy[2 * r] = e->int_mv_2nx2n[r].x; xy[2 * r + 1] = e->int_mv_2nx2n[r].y; } }
 const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }
 const HmoYuv *hmo_test_reco(const HmoEnc *e, int d, int best) { return best ? e->reco_best[d] : e->reco_temp[d]; }
 const HmoCabac *hmo_test_slot(const HmoEnc *e, int d, int ci) { return d < 0 ? &e->goon : &e->slot[d][ci]; }

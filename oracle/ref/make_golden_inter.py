@@ -43,10 +43,16 @@ CASES = {      # name: (generator, width, height, base QP, seed, pictures, searc
     "amp_mixed_qp30": ("mixed", 192, 128, 30, 13, 3, 16),          # AMP 1 + TZ + TMVP: the closest to the reference's lowdelay_P cfg the path gets
     "amp_shear_qp27": ("shear_textured", 192, 128, 27, 9, 3, 16),  # AMP + TZ on motion boundaries at CU quarters: asymmetric partitions win
     "amp_textured_qp27": ("textured", 136, 72, 27, 6, 3, 32),     # AMP, partial CTUs, full search
+    # several reference pictures (RefPicList0 = the last MREF decided pictures, most recent first): loop over reference indices in
+    # predInterSearch, ref_idx syntax, AMVP candidates scaled by POC distance (xAddMVPCandOrder), zero merge candidates per index
+    "mr2_mixed_qp30": ("mixed", 136, 72, 30, 17, 4, 16),           # two references, TZ search
+    "mr4_textured_qp32": ("textured", 128, 128, 32, 23, 6, 16),    # four references (the lowdelay cfg's count), TZ + TMVP (scaled collocated vectors)
+    "mr3_amp_shear_qp27": ("shear_textured", 128, 128, 27, 29, 5, 16),   # three references + AMP + TMVP, full search
 }
-FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1, "tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1, "amp_shear_qp27": 1}        # HM's FastSearch of a case (default 0 = full search)
-AMP = {"amp_mixed_qp30": 1, "amp_textured_qp27": 1, "amp_shear_qp27": 1}              # AMP on: asymmetric partitions at depths 0..2 (AMP_ENC_SPEEDUP + AMP_MRG selection)
-TMVP = {"tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1}           # TMVP on: the collocated picture is the reference picture
+FAST_SEARCH = {"tz_textured_qp32": 1, "tz_mixed_qp27": 1, "tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1, "amp_shear_qp27": 1, "mr2_mixed_qp30": 1, "mr4_textured_qp32": 1}        # HM's FastSearch of a case (default 0 = full search)
+AMP = {"amp_mixed_qp30": 1, "amp_textured_qp27": 1, "amp_shear_qp27": 1, "mr3_amp_shear_qp27": 1}              # AMP on: asymmetric partitions at depths 0..2 (AMP_ENC_SPEEDUP + AMP_MRG selection)
+TMVP = {"tmvp_mixed_qp30": 1, "tmvp_textured_qp35": 1, "amp_mixed_qp30": 1, "mr4_textured_qp32": 1, "mr3_amp_shear_qp27": 1}   # TMVP on: the collocated picture is the reference picture
+MREF = {"mr2_mixed_qp30": 2, "mr4_textured_qp32": 4, "mr3_amp_shear_qp27": 3}         # reference pictures in list 0 (default 1)
 
 
 def run_case(case, ref_factory, on_picture):
@@ -61,6 +67,8 @@ def run_case(case, ref_factory, on_picture):
     prev = None
     prev_ctus = None
     out = []
+    dpb = []                                                   # decided pictures: (poc, deblocked planes, Ctu array bytes, the POCs its list 0 named)
+    nref = MREF.get(case, 1)
     for poc in range(n_pic):
         f = st.moving_frame(synth, gen, w, h, seed, poc)
         stype, qp, lam = hmo_py.ldp_slice(poc, base_qp)
@@ -70,10 +78,21 @@ def run_case(case, ref_factory, on_picture):
             out.append((None, None))
         else:
             col = prev_ctus if TMVP.get(case, 0) else None
-            enc = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
-            ref = ref_factory(poc, f, qp, lam, prev, sr) if ref_factory else None
-            if ref and col is not None:
-                ref.setup_col(col, poc)
+            if nref > 1:
+                rl = dpb[-nref:][::-1]                            # RefPicList0: most recent first
+                pocs = [r[0] for r in rl]
+                enc = hmo_py.Encoder(*f, qp, refs=[r[1] for r in rl], ref_pocs=pocs, poc=poc, col=col, col_ref_pocs=rl[0][3] or [rl[0][0] - 1],
+                                     lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
+                ref = ref_factory(poc, f, qp, lam, [r[1] for r in rl], sr, pocs) if ref_factory else None
+                if ref and col is not None:
+                    ref.setup_col_multi(col, poc, rl[0][0], rl[0][3] or [rl[0][0] - 1])
+                cur_ref_pocs = pocs
+            else:
+                enc = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
+                ref = ref_factory(poc, f, qp, lam, prev, sr) if ref_factory else None
+                if ref and col is not None:
+                    ref.setup_col(col, poc)
+                cur_ref_pocs = [poc - 1]
             irec, mrec, bad = [], [], [0]
 
             def on_event(ev, depth, arg, enc=enc, ref=ref, irec=irec, mrec=mrec, bad=bad):
@@ -116,6 +135,7 @@ def run_case(case, ref_factory, on_picture):
         prev_ctus = enc.all_ctus_bytes()
         enc.deblock()
         prev = [a.copy() for a in enc.rec]
+        dpb.append((poc, prev, prev_ctus, cur_ref_pocs if poc else []))
         if poc == 0:
             on_picture(poc, enc, None, 0)
     return out
@@ -126,9 +146,12 @@ def one(case):
     gen, w, h, base_qp, seed, n_pic, sr = CASES[case]
     dbk, total_bad = {}, [0]
 
-    def ref_factory(poc, f, qp, lam, prev, sr):
+    def ref_factory(poc, f, qp, lam, prev, sr, pocs=None):
         r = st.RefSearch(w, h, qp, f, search_range=sr, fast_search=FAST_SEARCH.get(case, 0), amp=AMP.get(case, 0))
-        r.setup_p(prev, lam)
+        if pocs is None:
+            r.setup_p(prev, lam)
+        else:
+            r.setup_p_multi(prev, pocs, poc, lam)                # prev = the pictures of RefPicList0
         return r
 
     def on_picture(poc, enc, ref, bad):

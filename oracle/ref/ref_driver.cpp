@@ -581,6 +581,41 @@ int ref_setup_p(const unsigned char *ry, const unsigned char *ru, const unsigned
   g_trq->setLambdas(lambdas);
   return 0;
 }
+/* Several reference pictures: RefPicList0[k] = planes[3k..3k+2] at POC pocs[k] (k < n <= 4), the current picture at curPoc.
+ * The neighbours' and the slice's reference POCs come from TComSlice::setRefPOCList, as in TEncGOP.cpp:1006. */
+static TComPic *g_refpics[4] = { 0, 0, 0, 0 };
+int ref_setup_p_multi(int n, const unsigned char *const *planes, const int *pocs, int curPoc, double lambda)
+{
+  if (!g_pic || n < 1 || n > 4) return -1;
+  if (ref_setup_p(planes[0], planes[1], planes[2], lambda) != 0) return -1;
+  g_refpics[0] = g_refpic;
+  for (int k = 1; k < n; k++) {
+    if (!g_refpics[k]) { g_refpics[k] = new TComPic(); g_refpics[k]->create(g_sps, g_pps, 64, 64, 4, false); }
+    for (int c = 0; c < 3; c++) {
+      TComPicYuv *r = g_refpics[k]->getPicYuvRec(); const ComponentID id = ComponentID(c);
+      Pel *p = r->getAddr(id); const int s = r->getStride(id), w = r->getWidth(id), h = r->getHeight(id);
+      for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) p[y * s + x] = planes[3 * k + c][y * w + x];
+    }
+    g_refpics[k]->getPicYuvRec()->setBorderExtension(false);
+    g_refpics[k]->getPicYuvRec()->extendPicBorder();
+  }
+  for (int k = 0; k < n; k++) { g_refpics[k]->getSlice(0)->setPOC(pocs[k]); g_refpics[k]->setIsLongTerm(false); }
+  g_slice->setPOC(curPoc);
+  g_slice->setNumRefIdx(REF_PIC_LIST_0, n);
+  for (int k = 0; k < n; k++) g_slice->setRefPic(g_refpics[k], REF_PIC_LIST_0, k);
+  g_slice->setRefPOCList();
+  return 0;
+}
+/* TMVP with several references: the collocated picture (RefPicList0[0]) holds its own POC and the POCs its list 0 named */
+void ref_col_finish_multi(int curPoc, int colPoc, const int *colRefPocs, int n)
+{
+  g_refpic->compressMotion();
+  TComSlice *cs = g_refpic->getSlice(0);
+  cs->setPOC(colPoc);
+  for (int k = 0; k < n; k++) { cs->setRefPOC(colRefPocs[k], REF_PIC_LIST_0, k); cs->setIsUsedAsLongTerm(REF_PIC_LIST_0, k, false); }
+  g_slice->setPOC(curPoc); g_slice->setRefPOCList();
+  g_slice->setEnableTMVPFlag(true); g_slice->setColFromL0Flag(1); g_slice->setColRefIdx(0); g_slice->setCheckLDC(true);
+}
 /* TMVP: the reference picture as the collocated picture.  Its decided CTUs' prediction modes and list-0 motion are loaded,
  * TComPic::compressMotion is run on it (as TEncGOP does after a picture is coded, TEncGOP.cpp:1497) and the current slice
  * gets the collocated-picture syntax HM's lowdelay configuration produces (TMVP on, collocated_from_l0, collocated_ref_idx 0). */
@@ -680,7 +715,7 @@ void ref_set_slice_type(int isP) { g_slice->setSliceType(isP ? P_SLICE : I_SLICE
 
 /* TZ search (FastSearch 1) starts non-2Nx2N / deeper searches from the integer vector of the last 2Nx2N search
  * (m_integerMv2Nx2N, TEncSearch.cpp:3822-3833): encoder state that the caller carries over from its own search */
-void ref_set_int_mv(int x, int y) { g_search->m_integerMv2Nx2N[0][0].set(x, y); }
+void ref_set_int_mv(int refIdx, int x, int y) { g_search->m_integerMv2Nx2N[0][refIdx].set(x, y); }
 
 /* ---- sample adaptive offset: the reference's own TEncSampleAdaptiveOffset on the picture held by the driver -------------
  * PicYuvOrg / PicYuvRec (the deblocked picture) are loaded with ref_set_org / ref_set_rec.  The call sequence is TEncGOP's

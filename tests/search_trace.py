@@ -208,6 +208,30 @@ class RefSearch:
         self.base = st[:self.n_hm].copy()
         self.is_p = True
 
+    def setup_p_multi(self, refs, ref_pocs, poc, lam):
+        """slice type P with several reference pictures: RefPicList0[k] = refs[k] at POC ref_pocs[k], this picture at `poc`"""
+        vp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        self._keep = [np.ascontiguousarray(a) for r in refs for a in r]
+        arr = (C.c_void_p * len(self._keep))(*[a.ctypes.data for a in self._keep])
+        pocs = np.ascontiguousarray(ref_pocs, np.int32)
+        self.L.ref_setup_p_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        assert self.L.ref_setup_p_multi(len(refs), arr, pocs.ctypes.data, int(poc), float(lam)) == 0
+        self.L.ref_cabac_reset()
+        st = np.zeros(512, np.uint8)
+        self.L.ref_cabac_states(st.ctypes.data_as(C.c_void_p))
+        self.base = st[:self.n_hm].copy()
+        self.is_p = True
+
+    def setup_col_multi(self, ctus_bytes, poc, col_poc, col_ref_pocs):
+        """TMVP with several references: the collocated picture = refs[0], decided with the reference POCs `col_ref_pocs`"""
+        L, vp = self.L, lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        n = C.sizeof(hmo_py.Ctu)
+        for a in range(self.n_ctu):
+            c = hmo_py.Ctu.from_buffer_copy(ctus_bytes[a * n:(a + 1) * n])
+            L.ref_set_col_ctu(a, vp(np.ctypeslib.as_array(c.pred_mode).copy()), vp(np.ctypeslib.as_array(c.mv).copy()), vp(np.ctypeslib.as_array(c.ref_idx).copy()))
+        crp = np.ascontiguousarray(col_ref_pocs, np.int32)
+        L.ref_col_finish_multi(int(poc), int(col_poc), crp.ctypes.data_as(C.c_void_p), len(crp))
+
     def setup_col(self, ctus_bytes, poc):
         """TMVP: the reference picture's decided CTUs (Encoder.all_ctus_bytes()) become the collocated picture's motion field"""
         L, vp = self.L, lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
@@ -225,7 +249,8 @@ class RefSearch:
             c = enc.ctu_arrays(a)
             L.ref_set_ctu_inter(a, vp(c["skip"]), vp(c["inter_dir"]), vp(c["merge_flag"]), vp(c["mv"]), vp(c["ref_idx"]))
         if self.fast_search:                                    # TZ search state carried from the oracle's own search
-            L.ref_set_int_mv(*enc.test_int_mv())
+            for r, (x, y) in enumerate(enc.test_int_mv()):
+                L.ref_set_int_mv(r, x, y)
 
     def deblock(self, enc, beta=0, tc=0):
         """the reference's loopFilterPic on the oracle's decided picture (its arrays + un-filtered reconstruction)"""
