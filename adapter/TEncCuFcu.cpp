@@ -36,8 +36,12 @@ namespace {
 struct FcuState {
   fcu_ctx *ctx = nullptr;
   int width = 0, height = 0, n_ctu = 0;
-  uint8_t *d_org[3] = { nullptr, nullptr, nullptr }, *d_rec[3] = { nullptr, nullptr, nullptr }, *d_ref[3] = { nullptr, nullptr, nullptr };
+  uint8_t *d_org[3] = { nullptr, nullptr, nullptr }, *d_rec[3] = { nullptr, nullptr, nullptr };
   uint8_t *d_refsrc[3] = { nullptr, nullptr, nullptr };
+  /* padded reference pictures resident in HBM, keyed by POC: a picture is uploaded and padded once, however many later pictures
+   * name it (the lowdelay cfg keeps the GOP-boundary pictures for up to three GOPs) */
+  enum { N_SLOT = FCU_MAX_REF + 1 };
+  uint8_t *d_ref[N_SLOT][3] = {}; Int ref_poc[N_SLOT]; Bool ref_valid[N_SLOT] = {};
   fcu_ctu_out *d_out = nullptr;                                /* decisions of the picture being coded ...                          */
   fcu_ctu_out *d_out_prev = nullptr; Int poc_prev = -1 << 30;  /* ... and of the picture coded before it: the TMVP motion field     */
   std::vector<uint8_t> h_plane[3];
@@ -64,7 +68,8 @@ void ensure_context(const TComSPS *sps)
   size_t pad[3]; fcu_pad_sizes(S.ctx, pad);
   for (int c = 0; c < 3; c++) {
     HIPOK(hipMalloc((void **)&S.d_org[c], plane_bytes(w, h, c))); HIPOK(hipMalloc((void **)&S.d_rec[c], plane_bytes(w, h, c)));
-    HIPOK(hipMalloc((void **)&S.d_refsrc[c], plane_bytes(w, h, c))); HIPOK(hipMalloc((void **)&S.d_ref[c], pad[c]));
+    HIPOK(hipMalloc((void **)&S.d_refsrc[c], plane_bytes(w, h, c)));
+    for (int k = 0; k < FcuState::N_SLOT; k++) { HIPOK(hipMalloc((void **)&S.d_ref[k][c], pad[c])); S.ref_valid[k] = false; }
     S.h_plane[c].resize(plane_bytes(w, h, c));
   }
   HIPOK(hipMalloc((void **)&S.d_out, sizeof(fcu_ctu_out) * (size_t)S.n_ctu));
@@ -90,6 +95,7 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
     upload(pic->getPicYuvOrg(), S.d_org);
     std::swap(S.d_out, S.d_out_prev); S.poc_prev = S.poc_loaded;
     S.poc_loaded = pic->getPOC();
+    for (int k = 0; k < FcuState::N_SLOT; k++) if (S.ref_valid[k] && S.ref_poc[k] == S.poc_loaded) S.ref_valid[k] = false;   /* a POC coded again (new IDR period) */
   }
   fcu_frame_params fp;
   fcu_default_frame_params(&fp, slice->getSliceQp());
@@ -103,7 +109,7 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
   const int count = (int)(slice->getSliceCurEndCtuTsAddr() - slice->getSliceCurStartCtuTsAddr());
   fp.slice_ctus = cfg->getSliceMode() == FIXED_NUMBER_OF_CTU ? cfg->getSliceArgument() : 0;
   if (!slice->isIntra()) {
-    if (slice->isInterB() || slice->getNumRefIdx(REF_PIC_LIST_0) != 1) { fprintf(stderr, "TEncCuFcu: P slices with one reference picture only\n"); exit(1); }
+    if (slice->isInterB() || slice->getNumRefIdx(REF_PIC_LIST_0) < 1 || slice->getNumRefIdx(REF_PIC_LIST_0) > FCU_MAX_REF) { fprintf(stderr, "TEncCuFcu: P slices with 1..%d reference pictures only\n", FCU_MAX_REF); exit(1); }
     fp.slice_type = FCU_SLICE_P;
     fp.search_range = cfg->getSearchRange(); fp.fast_enc = cfg->getUseFastEnc(); fp.hadamard_me = cfg->getUseHADME();
     fp.fast_merge_decision = cfg->getUseFastDecisionForMerge(); fp.max_merge_cand = slice->getMaxNumMergeCand();
@@ -116,25 +122,43 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
   }
   int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
   if (rc != FCU_OK) die("fcu_chain_begin", rc);
-  if (fp.slice_type == FCU_SLICE_P) {                           /* list 0, index 0: the filtered reconstruction HM holds */
-    upload(slice->getRefPic(REF_PIC_LIST_0, 0)->getPicYuvRec(), S.d_refsrc);
-    rc = fcu_pad_reference(S.ctx, S.d_refsrc[0], S.d_refsrc[1], S.d_refsrc[2], S.d_ref[0], S.d_ref[1], S.d_ref[2], nullptr);
-    if (rc != FCU_OK) die("fcu_pad_reference", rc);
-    rc = fcu_chain_set_reference(S.ctx, 0, S.d_ref[0], S.d_ref[1], S.d_ref[2]);
-    if (rc != FCU_OK) die("fcu_chain_set_reference", rc);
+  if (fp.slice_type == FCU_SLICE_P) {                           /* list 0: the filtered reconstructions HM holds */
+    const int nRef = slice->getNumRefIdx(REF_PIC_LIST_0);
+    const uint8_t *planes[3 * FCU_MAX_REF]; int pocs[FCU_MAX_REF], slot[FCU_MAX_REF];
+    for (int r = 0; r < nRef; r++) {
+      pocs[r] = slice->getRefPOC(REF_PIC_LIST_0, r); slot[r] = -1;
+      for (int k = 0; k < FcuState::N_SLOT; k++) if (S.ref_valid[k] && S.ref_poc[k] == pocs[r]) slot[r] = k;
+    }
+    for (int r = 0; r < nRef; r++) {
+      if (slot[r] < 0) {                                        /* not resident yet: a slot no picture of this list occupies */
+        int k = 0;
+        for (; k < FcuState::N_SLOT; k++) { bool used = false; for (int q = 0; q < nRef; q++) used |= slot[q] == k; if (!used) break; }
+        upload(slice->getRefPic(REF_PIC_LIST_0, r)->getPicYuvRec(), S.d_refsrc);
+        rc = fcu_pad_reference(S.ctx, S.d_refsrc[0], S.d_refsrc[1], S.d_refsrc[2], S.d_ref[k][0], S.d_ref[k][1], S.d_ref[k][2], nullptr);
+        if (rc != FCU_OK) die("fcu_pad_reference", rc);
+        S.ref_poc[k] = pocs[r]; S.ref_valid[k] = true; slot[r] = k;
+      }
+      for (int c = 0; c < 3; c++) planes[3 * r + c] = S.d_ref[slot[r]][c];
+    }
+    rc = fcu_chain_set_references(S.ctx, 0, nRef, planes, pocs, slice->getPOC());
+    if (rc != FCU_OK) die("fcu_chain_set_references", rc);
     if (fp.tmvp) {
-      /* collocated picture = list 0, collocated_ref_idx: with one reference picture that is the picture coded before this
-       * one, whose fcu_ctu_out array is still in HBM.  The engine applies no vector scaling: both POC distances (picture ->
-       * reference, collocated picture -> its reference) must be equal, as they are in a one-reference low-delay chain. */
+      /* collocated picture = list 0, collocated_ref_idx 0 (the encoder's choice for low-delay P): the picture coded before this
+       * one, whose fcu_ctu_out array is still in HBM.  Its own list 0 gives the POCs its vectors point at; the engine scales by
+       * the two POC distances (TComDataCU::xGetColMVP, TComDataCU.cpp:3242-3310). */
       TComPic *col = slice->getRefPic(RefPicList(slice->getColFromL0Flag() ? 0 : 1), slice->getColRefIdx());
-      const Int dCur = slice->getPOC() - slice->getRefPOC(REF_PIC_LIST_0, 0);
       TComSlice *cs = col->getSlice(0);
-      const Bool colInter = !cs->isIntra();
-      if (col->getPOC() != S.poc_prev || (colInter && (cs->getNumRefIdx(REF_PIC_LIST_0) != 1 || col->getPOC() - cs->getRefPOC(REF_PIC_LIST_0, 0) != dCur))) {
-        fprintf(stderr, "TEncCuFcu: TMVP needs the collocated picture to be the previously coded picture at the same POC distance\n"); exit(1);
+      if (!slice->getColFromL0Flag() || slice->getColRefIdx() != 0 || col->getPOC() != S.poc_prev || (!cs->isIntra() && cs->getNumRefIdx(REF_PIC_LIST_0) > FCU_MAX_REF)) {
+        fprintf(stderr, "TEncCuFcu: TMVP needs the collocated picture to be list 0 index 0 and the previously coded picture\n"); exit(1);
       }
       rc = fcu_chain_set_collocated(S.ctx, 0, S.d_out_prev);
       if (rc != FCU_OK) die("fcu_chain_set_collocated", rc);
+      if (!cs->isIntra()) {
+        int cp[FCU_MAX_REF]; const int n = cs->getNumRefIdx(REF_PIC_LIST_0);
+        for (int k = 0; k < n; k++) cp[k] = cs->getRefPOC(REF_PIC_LIST_0, k);
+        rc = fcu_chain_set_collocated_pocs(S.ctx, 0, col->getPOC(), cp, n);
+        if (rc != FCU_OK) die("fcu_chain_set_collocated_pocs", rc);
+      }
     }
   }
   if (fp.slice_ctus > 0) { rc = fcu_chain_set_range(S.ctx, 0, first, count); if (rc != FCU_OK) die("fcu_chain_set_range", rc); }
@@ -170,7 +194,8 @@ Void TEncCu::create(UChar uhTotalDepth, UInt, UInt, ChromaFormat)
 Void TEncCu::destroy()
 {
   FcuState &S = g_fcu;
-  for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_ref[c]); hipFree(S.d_refsrc[c]); S.d_org[c] = S.d_rec[c] = S.d_ref[c] = S.d_refsrc[c] = nullptr; }
+  for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_refsrc[c]); S.d_org[c] = S.d_rec[c] = S.d_refsrc[c] = nullptr;
+    for (int k = 0; k < FcuState::N_SLOT; k++) { hipFree(S.d_ref[k][c]); S.d_ref[k][c] = nullptr; S.ref_valid[k] = false; } }
   hipFree(S.d_out); hipFree(S.d_out_prev); S.d_out = S.d_out_prev = nullptr; S.poc_prev = -1 << 30;
   if (S.ctx) { fcu_destroy(S.ctx); S.ctx = nullptr; }
   S.width = S.height = 0; S.poc_loaded = -1 << 30;

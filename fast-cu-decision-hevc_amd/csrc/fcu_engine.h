@@ -238,8 +238,15 @@ struct Chain {
   const int16_t *obf;
   double ver[4][6];
   const fcu_ctu_out *col;      /* TMVP: the reference picture's fcu_ctu_out array (its motion field), or null */
-  int int_mv[2];               /* m_integerMv2Nx2N[list 0][ref 0]: integer vector of the chain's last 2Nx2N motion search (TZ search start point) */
+  int int_mv[2];               /* (kept for layout; the TZ start vectors live in int_mv_r below) */
   fcu_pu_trace *pu_trace;      /* optional [n_ctu][FCU_PUS_PER_CTU] record of the luma search (fcu_chain_set_pu_trace) */
+  /* reference picture list 0 of a P slice: refs[r] = padded planes of RefPicList0[r] (refs[0] == ref; all share ref_stride),
+   * ref_poc[r] its POC, poc the current picture's, n_ref = num_ref_idx_l0_active (1..FCU_MAX_REF).  col_poc / col_ref_poc: the
+   * collocated picture (= RefPicList0[0]) and the POCs its own list 0 named, for the TMVP scaling (xGetColMVP).
+   * int_mv_r[r] = m_integerMv2Nx2N[list 0][r]: integer vector of the chain's last 2Nx2N motion search on that reference. */
+  const uint8_t *refs[FCU_MAX_REF][3];
+  int n_ref, poc, ref_poc[FCU_MAX_REF], col_poc, col_ref_poc[FCU_MAX_REF];
+  int int_mv_r[FCU_MAX_REF][2];
 };
 enum { DEC_TRAINING = 0, DEC_VERIFYING = 1, DEC_TESTING = 2 };
 

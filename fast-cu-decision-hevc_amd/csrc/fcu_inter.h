@@ -90,7 +90,22 @@ FCU_DEV int same_motion(const Nb &a, const Nb &b) { return a.mvx == b.mvx && a.m
  * (TComDataCU.cpp:3175-3242): the motion its fcu_ctu_out array holds at the top-left 4x4 partition of the 16x16 block that
  * contains the position (what TComPic::compressMotion keeps); unavailable where that partition is intra.  One reference,
  * consecutive pictures: both POC distances are 1, no scaling. */
-FCU_DEV int col_mvp(const Env E, int x, int y, int &mvx, int &mvy)
+/* xGetDistScaleFactor (TComDataCU.cpp:3312-3329) and TComMv::scaleMv (TComMv.h:145-150): vectors of neighbours / of the
+ * collocated picture that point at another reference picture are scaled by the ratio of the POC distances */
+FCU_DEV int dist_scale(int curPoc, int curRefPoc, int colPoc, int colRefPoc)
+{
+  const int dD = colPoc - colRefPoc, dB = curPoc - curRefPoc;
+  if (dD == dB) return 4096;
+  const int tdb = clip3i(-128, 127, dB), tdd = clip3i(-128, 127, dD);
+  const int x = (0x4000 + iabs(tdd / 2)) / tdd;
+  return clip3i(-4096, 4095, (tdb * x + 32) >> 6);
+}
+FCU_DEV void scale_mv(int sc, int &x, int &y)
+{
+  if (sc == 4096) return;
+  x = clip3i(-32768, 32767, (sc * x + 127 + (sc * x < 0)) >> 8); y = clip3i(-32768, 32767, (sc * y + 127 + (sc * y < 0)) >> 8);
+}
+FCU_DEV int col_mvp(const Env E, int x, int y, int refIdx, int &mvx, int &mvy)
 {
   const fcu_ctu_out *col = E.C->col;
   if (!col) return 0;
@@ -99,15 +114,17 @@ FCU_DEV int col_mvp(const Env E, int x, int y, int &mvx, int &mvy)
   const int z = zidx_of(xc & 63, yc & 63);
   if (c->pred_mode[z] != MODE_INTER || c->ref_idx[z] < 0) return 0;
   mvx = c->mv[z][0]; mvy = c->mv[z][1];
+  const int cr = c->ref_idx[z] < FCU_MAX_REF ? c->ref_idx[z] : 0;
+  scale_mv(dist_scale(E.C->poc, E.C->ref_poc[refIdx], E.C->col_poc, E.C->col_ref_poc[cr]), mvx, mvy);
   return 1;
 }
 /* bottom-right neighbour H when inside the picture and the CTU row (:2528-2563 / :2863-2900), else the PU centre */
-FCU_DEV int temporal_candidate(const Env E, int xP, int yP, int w, int h, int &mvx, int &mvy)
+FCU_DEV int temporal_candidate(const Env E, int xP, int yP, int w, int h, int refIdx, int &mvx, int &mvy)
 {
   if (!E.C->p.tmvp) return 0;
   const int bx = xP + w, by = yP + h;
-  if (bx < E.C->p.width && by < E.C->p.height && (by & 63) != 0 && col_mvp(E, bx, by, mvx, mvy)) return 1;
-  return col_mvp(E, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), mvx, mvy);
+  if (bx < E.C->p.width && by < E.C->p.height && (by & 63) != 0 && col_mvp(E, bx, by, refIdx, mvx, mvy)) return 1;
+  return col_mvp(E, xP + ((w >> 3) << 2), yP + ((h >> 3) << 2), refIdx, mvx, mvy);
 }
 
 FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
@@ -134,33 +151,51 @@ FCU_DEV FCU_NOINLINE void merge_candidates(const CuObj *cu, int ps, int pu)
     const Nb b2 = nb_motion(E, cu, xP - 1, yP - 1, xP, yP);
     if (b2.avail && b2.inter && (!okA1 || !same_motion(a1, b2)) && (!okB1 || !same_motion(b1, b2))) FCU_ADD_MRG(b2);
   }
-  if (n < maxc) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, tx, ty)) { g_S.mrg_mv[n][0] = tx; g_S.mrg_mv[n][1] = ty; g_S.mrg_ref[n] = 0; n++; } }
-  while (n < maxc) { g_S.mrg_mv[n][0] = g_S.mrg_mv[n][1] = 0; g_S.mrg_ref[n] = 0; n++; }
+  if (n < maxc) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, 0, tx, ty)) { g_S.mrg_mv[n][0] = tx; g_S.mrg_mv[n][1] = ty; g_S.mrg_ref[n] = 0; n++; } }   /* references index 0 (:2566) */
+  for (int r = 0, refcnt = 0; n < maxc; n++) {               /* zero candidates walk the reference indices (:2672-2686) */
+    g_S.mrg_mv[n][0] = g_S.mrg_mv[n][1] = 0; g_S.mrg_ref[n] = r;
+    if (refcnt == E.C->n_ref - 1) r = 0; else { ++r; ++refcnt; }
+  }
 #undef FCU_ADD_MRG
 }
-/* fillMvpCand (one reference picture) -> g_S.amvp; one lane */
-FCU_DEV FCU_NOINLINE void amvp_candidates(const CuObj *cu, int ps, int pu)
+/* fillMvpCand (TComDataCU.cpp:2781-2925) for RefPicList0[refIdx] -> g_S.amvp; one lane.  The left pair (A0, A1) and the above
+ * triple (B0, B1, B2), each first for a neighbour that references the same picture (xAddMVPCand), then -- left: if that found
+ * nothing; above: only if no left neighbour was inter -- any inter neighbour with its vector scaled by the POC distances
+ * (xAddMVPCandOrder); equal pair pruned, temporal candidate appended, cut / padded to two. */
+FCU_DEV int mvp_same(const Env E, const Nb &nb, int refIdx, int (*c)[2], int &n)
+{ if (nb.avail && nb.ref >= 0 && E.C->ref_poc[nb.ref] == E.C->ref_poc[refIdx]) { c[n][0] = nb.mvx; c[n][1] = nb.mvy; n++; return 1; } return 0; }
+FCU_DEV int mvp_scaled(const Env E, const Nb &nb, int refIdx, int (*c)[2], int &n)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  if (!(nb.avail && nb.ref >= 0)) return 0;
+  int x = nb.mvx, y = nb.mvy; scale_mv(dist_scale(E.C->poc, E.C->ref_poc[refIdx], E.C->poc, E.C->ref_poc[nb.ref]), x, y);
+  c[n][0] = x; c[n][1] = y; n++; return 1;
+}
+FCU_DEV FCU_NOINLINE void amvp_candidates(const CuObj *cu, int ps, int pu, int refIdx)
+{
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); refIdx = FCU_UNI(refIdx);
   const Pu g = pu_geom(cu->depth_cu, ps, pu);
   const int xP = cu->x + g.ox, yP = cu->y + g.oy, w = g.w, h = g.h;
   const int lbx = xP, lby = yP + h - 1, rtx = xP + w - 1, rty = yP;
-  int n = 0;
+  int n = 0; int c3[4][2];
   const Nb a0 = nb_motion(E, cu, xP - 1, yP + h, lbx, lby), a1 = nb_motion(E, cu, xP - 1, yP + h - 1, lbx, lby);
   const int addedSmvp = (a0.avail && a0.inter) || (a1.avail && a1.inter);
-  if (a0.avail && a0.ref >= 0) { g_S.amvp[n][0] = a0.mvx; g_S.amvp[n][1] = a0.mvy; n++; }
-  else if (a1.avail && a1.ref >= 0) { g_S.amvp[n][0] = a1.mvx; g_S.amvp[n][1] = a1.mvy; n++; }
+  int added = mvp_same(E, a0, refIdx, c3, n);
+  if (!added) added = mvp_same(E, a1, refIdx, c3, n);
+  if (!added) { added = mvp_scaled(E, a0, refIdx, c3, n); if (!added) mvp_scaled(E, a1, refIdx, c3, n); }
   const Nb b0 = nb_motion(E, cu, xP + w, yP - 1, rtx, rty), b1 = nb_motion(E, cu, xP + w - 1, yP - 1, rtx, rty), b2 = nb_motion(E, cu, xP - 1, yP - 1, xP, yP);
-  int ax = 0, ay = 0, haveAbove = 1;
-  if (b0.avail && b0.ref >= 0) { ax = b0.mvx; ay = b0.mvy; }
-  else if (b1.avail && b1.ref >= 0) { ax = b1.mvx; ay = b1.mvy; }
-  else if (b2.avail && b2.ref >= 0) { ax = b2.mvx; ay = b2.mvy; }
-  else haveAbove = 0;
-  if (haveAbove) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }
-  if (!addedSmvp && haveAbove && n < 2) { g_S.amvp[n][0] = ax; g_S.amvp[n][1] = ay; n++; }        /* xAddMVPCandOrder repeats it */
-  if (n == 2 && g_S.amvp[0][0] == g_S.amvp[1][0] && g_S.amvp[0][1] == g_S.amvp[1][1]) n = 1;
-  if (n < 2) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, tx, ty)) { g_S.amvp[n][0] = tx; g_S.amvp[n][1] = ty; n++; } }   /* appended, then the list is cut to two */
-  while (n < 2) { g_S.amvp[n][0] = g_S.amvp[n][1] = 0; n++; }
+  added = mvp_same(E, b0, refIdx, c3, n);
+  if (!added) added = mvp_same(E, b1, refIdx, c3, n);
+  if (!added) mvp_same(E, b2, refIdx, c3, n);
+  if (!addedSmvp) {
+    added = mvp_scaled(E, b0, refIdx, c3, n);
+    if (!added) added = mvp_scaled(E, b1, refIdx, c3, n);
+    if (!added) mvp_scaled(E, b2, refIdx, c3, n);
+  }
+  if (n == 2 && c3[0][0] == c3[1][0] && c3[0][1] == c3[1][1]) n = 1;
+  if (n < 3) { int tx, ty; if (temporal_candidate(E, xP, yP, w, h, refIdx, tx, ty)) { c3[n][0] = tx; c3[n][1] = ty; n++; } }
+  if (n > 2) n = 2;
+  while (n < 2) { c3[n][0] = c3[n][1] = 0; n++; }
+  g_S.amvp[0][0] = c3[0][0]; g_S.amvp[0][1] = c3[0][1]; g_S.amvp[1][0] = c3[1][0]; g_S.amvp[1][1] = c3[1][1];
 }
 FCU_DEV void clip_mv(const Params &P, const CuObj *cu, int &x, int &y)            /* clipMv, TComDataCU.cpp:2930-2942 */
 {
@@ -203,9 +238,9 @@ FCU_DEV int interp_sample(const uint8_t *ref, int rs, int comp, int x, int y, in
   return clip8((s + 2048) >> 12);
 }
 /* block of the component plane at (bx, by), size w x h, displaced by mv -> dst (all lanes; caller supplies the phase) */
-FCU_DEV void mc_block_lanes(const Env E, int lane, int comp, int bx, int by, int w, int h, int mvx, int mvy, uint8_t *dst, int ds)
+FCU_DEV void mc_block_lanes(const Env E, int lane, int refIdx, int comp, int bx, int by, int w, int h, int mvx, int mvy, uint8_t *dst, int ds)
 {
-  const uint8_t *ref = E.C->ref[comp]; const int rs = E.C->ref_stride[comp];
+  const uint8_t *ref = E.C->refs[refIdx][comp]; const int rs = E.C->ref_stride[comp];
   for (int i = lane; i < w * h; i += 64) { const int y = i / w, x = i - y * w; dst[y * ds + x] = (uint8_t)interp_sample(ref, rs, comp, bx + x, by + y, mvx, mvy); }
 }
 /* motionCompensation of one PU into a CU-sized buffer (the vector is clipped first, xPredInterUni) */
@@ -214,12 +249,13 @@ FCU_DEV FCU_NOINLINE void mc_pu(const CuObj *cu, int ps, int pu, Yuv *dst, int l
   const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); dst = FCU_UNI(dst); lumaOnly = FCU_UNI(lumaOnly);
   const Pu g = pu_geom(cu->depth_cu, ps, pu);
   int mvx = FCU_UNI((int)cu->mv[g.addr][0]), mvy = FCU_UNI((int)cu->mv[g.addr][1]);
+  int r = FCU_UNI((int)cu->ref_idx[g.addr]); if (r < 0) r = 0;
   clip_mv(E.C->p, cu, mvx, mvy);
   FCU_FOR_LANES {
-    mc_block_lanes(E, lane, 0, cu->x + g.ox, cu->y + g.oy, g.w, g.h, mvx, mvy, dst->y + g.oy * 64 + g.ox, 64);
+    mc_block_lanes(E, lane, r, 0, cu->x + g.ox, cu->y + g.oy, g.w, g.h, mvx, mvy, dst->y + g.oy * 64 + g.ox, 64);
     if (!lumaOnly) {
-      mc_block_lanes(E, lane, 1, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->u + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
-      mc_block_lanes(E, lane, 2, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->v + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
+      mc_block_lanes(E, lane, r, 1, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->u + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
+      mc_block_lanes(E, lane, r, 2, (cu->x + g.ox) >> 1, (cu->y + g.oy) >> 1, g.w >> 1, g.h >> 1, mvx, mvy, dst->v + (g.oy >> 1) * 32 + (g.ox >> 1), 32);
     }
   }
 }
@@ -301,19 +337,19 @@ FCU_DEV FCU_NOINLINE uint32_t inter_pred_error(const CuObj *cu, int ps, int pu)
 }
 
 /* ---- xEstimateMvPredAMVP + xGetTemplateCost: best of the two candidates -> returns its index (uniform) */
-FCU_DEV FCU_NOINLINE int estimate_mvp(const CuObj *cu, int ps, int pu)
+FCU_DEV FCU_NOINLINE int estimate_mvp(const CuObj *cu, int ps, int pu, int refIdx)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu);
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); refIdx = FCU_UNI(refIdx);
   const Params &P = E.C->p;
   const Pu g = pu_geom(cu->depth_cu, ps, pu);
-  FCU_SERIAL { amvp_candidates(cu, ps, pu); g_S.acc[0] = g_S.acc[1] = 0; }
+  FCU_SERIAL { amvp_candidates(cu, ps, pu, refIdx); g_S.acc[0] = g_S.acc[1] = 0; }
   const uint8_t *org = E.G->org[cu->depth_cu].y + g.oy * 64 + g.ox;
   for (int i = 0; i < 2; i++) {
     int cx = FCU_UNI(g_S.amvp[i][0]), cy = FCU_UNI(g_S.amvp[i][1]);
     clip_mv(P, cu, cx, cy);
     FCU_FOR_LANES {
       uint32_t s = 0;
-      for (int k = lane; k < g.w * g.h; k += 64) { const int y = k / g.w, x = k - y * g.w; s += (uint32_t)iabs(org[y * 64 + x] - interp_sample(E.C->ref[0], E.C->ref_stride[0], 0, cu->x + g.ox + x, cu->y + g.oy + y, cx, cy)); }
+      for (int k = lane; k < g.w * g.h; k += 64) { const int y = k / g.w, x = k - y * g.w; s += (uint32_t)iabs(org[y * 64 + x] - interp_sample(E.C->refs[refIdx][0], E.C->ref_stride[0], 0, cu->x + g.ox + x, cu->y + g.oy + y, cx, cy)); }
       FCU_WAVE_ADD(&g_S.acc[i], s);
     }
   }
@@ -466,14 +502,14 @@ FCU_DEV void tz_search(const Params &P, const CuObj *cu, const TzCtx &t, int ltx
   }
 }
 
-FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int predx, int predy, uint32_t bitsIn)
+FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int refIdx, int predx, int predy, uint32_t bitsIn)
 {
-  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); predx = FCU_UNI(predx); predy = FCU_UNI(predy); bitsIn = FCU_UNI(bitsIn);
+  const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); pu = FCU_UNI(pu); refIdx = FCU_UNI(refIdx); predx = FCU_UNI(predx); predy = FCU_UNI(predy); bitsIn = FCU_UNI(bitsIn);
   const Params &P = E.C->p; Scratch *G = E.G;
   const Pu g = pu_geom(cu->depth_cu, ps, pu);
   const uint8_t *org = G->org[cu->depth_cu].y + g.oy * 64 + g.ox;
   const int px = cu->x + g.ox, py = cu->y + g.oy, rng = P.search_range, rs = E.C->ref_stride[0];
-  const uint8_t *ref0 = E.C->ref[0];
+  const uint8_t *ref0 = E.C->refs[refIdx][0];
   /* xSetSearchRange */
   int cx = predx, cy = predy; clip_mv(P, cu, cx, cy);
   int ltx = cx - (rng << 2), lty = cy - (rng << 2), rbx = cx + (rng << 2), rby = cy + (rng << 2);
@@ -485,9 +521,9 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   if (P.fast_search) {                                       /* xPatternSearchFast -> xTZSearch; m_integerMv2Nx2N, TEncSearch.cpp:3822-3833 */
     TzCtx t; t.org = org; t.ref0 = ref0; t.rs = rs; t.px = px; t.py = py; t.w = g.w; t.h = g.h; t.step = step; t.predx = predx; t.predy = predy;
     const int usePred = ps != SIZE_2Nx2N || cu->depth_cu != 0;
-    tz_search(P, cu, t, ltx, lty, rbx, rby, usePred, FCU_UNI(E.C->int_mv[0]), FCU_UNI(E.C->int_mv[1]));
+    tz_search(P, cu, t, ltx, lty, rbx, rby, usePred, FCU_UNI(E.C->int_mv_r[refIdx][0]), FCU_UNI(E.C->int_mv_r[refIdx][1]));
     bx = FCU_UNI(g_S.tz_bx); by = FCU_UNI(g_S.tz_by);
-    if (ps == SIZE_2Nx2N) FCU_SERIAL { E.C->int_mv[0] = bx; E.C->int_mv[1] = by; }
+    if (ps == SIZE_2Nx2N) FCU_SERIAL { E.C->int_mv_r[refIdx][0] = bx; E.C->int_mv_r[refIdx][1] = by; }
   } else {
   FCU_SERIAL g_S.me_best = ~0ull;
   FCU_FOR_LANES {                                            /* one candidate position per lane */
@@ -595,13 +631,19 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
   const int normalMC = !(useMrg && (CTU >> d) > 8 && npu == 2);   /* AMP_MRG: merge estimation only (TEncSearch.cpp:3098-3103) */
   for (int pu = 0; pu < npu; pu++) {
     const uint32_t mbBits = (ps == SIZE_2Nx2N || ps == SIZE_NxN) ? 1 : 3;      /* xGetBlkBits, P slice */
-    int mvx = 0, mvy = 0; uint32_t bitsT = mbBits;
+    int mvx = 0, mvy = 0, refBest = 0; uint32_t bitsT = mbBits;
     if (!normalMC) {                                         /* the cleared motion field (:3356-3363) */
       FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, 0, 0, -1); pu_set_info(cu, ps, pu, lane, 0, 0, 0, 0, -1); }
     } else {
-    FCU_TIC(p5_); int mvpIdx = estimate_mvp(cu, ps, pu); FCU_ITOC(E, p5_, 5);
+    /* uni-directional prediction, list 0: every reference index in turn, the first strictly cheapest wins (:3110-3190) */
+    const int nRef = FCU_UNI(E.C->n_ref);
+    uint32_t costBest = 0xffffffffu; int bMvx = 0, bMvy = 0, bPredx = 0, bPredy = 0, bMvp = 0; uint32_t bBits = mbBits;
+    for (int refIdx = 0; refIdx < nRef; refIdx++) {
+    uint32_t refBits = mbBits;
+    if (nRef > 1) { refBits += (uint32_t)refIdx + 1; if (refIdx == nRef - 1) refBits--; }      /* ref_idx bins (:3114-3121) */
+    FCU_TIC(p5_); int mvpIdx = estimate_mvp(cu, ps, pu, refIdx); FCU_ITOC(E, p5_, 5);
     int predx = FCU_UNI(g_S.amvp[mvpIdx][0]), predy = FCU_UNI(g_S.amvp[mvpIdx][1]);
-    { FCU_TIC(p_); motion_estimation(cu, ps, pu, predx, predy, mbBits + 1); FCU_ITOC(E, p_, 6); }
+    { FCU_TIC(p_); motion_estimation(cu, ps, pu, refIdx, predx, predy, refBits + 1); FCU_ITOC(E, p_, 6); }
     mvx = FCU_UNI(g_S.me_out[0]); mvy = FCU_UNI(g_S.me_out[1]);
     bitsT = FCU_UNI(g_S.acc[12]); uint32_t costT = FCU_UNI(g_S.acc[13]);
     {                                                        /* xCheckBestMVP */
@@ -619,7 +661,11 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
         costT = (costT - motion_cost(P, org)) + motion_cost(P, bitsT);
       }
     }
-    FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); pu_set_info(cu, ps, pu, lane, 0, 0, mvx - predx, mvy - predy, mvpIdx); }
+    if (costT < costBest) { costBest = costT; bMvx = mvx; bMvy = mvy; bPredx = predx; bPredy = predy; bMvp = mvpIdx; bBits = bitsT; refBest = refIdx; }
+    }
+    mvx = bMvx; mvy = bMvy; bitsT = bBits;
+    { const int predx = bPredx, predy = bPredy, mvpIdx = bMvp, rb = refBest;
+      FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, rb); pu_set_info(cu, ps, pu, lane, 0, 0, mvx - predx, mvy - predy, mvpIdx); } }
     }
     FCU_TIC(p7_);
     if (ps != SIZE_2Nx2N) {                                  /* merge estimation of the PU (TEncSearch.cpp:3448-3498) */
@@ -627,7 +673,7 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
        * earlier candidate's vector (the usual case under coherent motion) reuse the error instead of predicting again */
       int seenX[6], seenY[6], seenR[6], nSeen = 0; uint32_t seenE[6];
       uint32_t meCost = 0xffffffffu;
-      if (normalMC) { const uint32_t e = inter_pred_error(cu, ps, pu); meCost = e + motion_cost(P, bitsT); seenX[0] = mvx; seenY[0] = mvy; seenR[0] = 0; seenE[0] = e; nSeen = 1; }
+      if (normalMC) { const uint32_t e = inter_pred_error(cu, ps, pu); meCost = e + motion_cost(P, bitsT); seenX[0] = mvx; seenY[0] = mvy; seenR[0] = refBest; seenE[0] = e; nSeen = 1; }
       FCU_SERIAL merge_candidates(cu, ps, pu);
       uint32_t mrgCost = 0xffffffffu; int mrgIdx = 0;
       const int nc = P.max_merge_cand;
@@ -653,7 +699,8 @@ FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
         const int cx = FCU_UNI(g_S.mrg_mv[mrgIdx][0]), cy = FCU_UNI(g_S.mrg_mv[mrgIdx][1]), cr = FCU_UNI(g_S.mrg_ref[mrgIdx]);
         FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, cx, cy, cr); pu_set_info(cu, ps, pu, lane, 1, mrgIdx, 0, 0, -1); }
       } else {
-        FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, 0); const int n = cu->nparts; for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) { cu->merge_flag[i] = 0; cu->merge_idx[i] = 0; cu->inter_dir[i] = 1; } }
+        const int rb = refBest;
+        FCU_FOR_LANES { pu_set_motion(cu, ps, pu, lane, mvx, mvy, rb); const int n = cu->nparts; for (int i = lane; i < n; i += 64) if (pu_covers(n, ps, pu, i)) { cu->merge_flag[i] = 0; cu->merge_idx[i] = 0; cu->inter_dir[i] = 1; } }
       }
     }
     FCU_ITOC(E, p7_, 7);
@@ -688,6 +735,19 @@ FCU_DEV void code_part_size_inter(const Env E, int c, const CuObj *cu, int part,
   }
 }
 FCU_DEV int ep_exgolomb_bins(uint32_t symbol, uint32_t count) { int n = 0; while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; } return n + 1 + (int)count; }
+/* codeRefFrmIdx, TEncSbac.cpp:743-775: first bin on context 0, second on context 1, the rest bypass (truncated unary) */
+FCU_DEV void code_ref_idx(int c, int refIdx, int nRef)
+{
+  cab_bin(c, refIdx == 0 ? 0 : 1, CTX_REF);
+  if (refIdx > 0) {
+    const int refNum = nRef - 2; refIdx--;
+    for (int ui = 0; ui < refNum; ui++) {
+      const int sym = ui == refIdx ? 0 : 1;
+      if (ui == 0) cab_bin(c, sym, CTX_REF + 1); else cab_ep(c, 1);
+      if (!sym) break;
+    }
+  }
+}
 FCU_DEV void code_mvd(int c, int hor, int ver)                                             /* TEncSbac.cpp:780-830 */
 {
   cab_bin(c, hor != 0, CTX_MVD); cab_bin(c, ver != 0, CTX_MVD);
@@ -704,7 +764,7 @@ FCU_DEV void code_pu_wise(const Env E, int c, const CuObj *cu, int part)        
   for (int pu = 0, sp = part; pu < npu; pu++, sp += off) {
     cab_bin(c, cu->merge_flag[sp], CTX_MERGE_FLAG);
     if (cu->merge_flag[sp]) code_merge_index(E, c, cu, sp);
-    else { code_mvd(c, cu->mvd[sp][0], cu->mvd[sp][1]); cab_bin(c, cu->mvp_idx[sp], CTX_MVP_IDX); }
+    else { if (E.C->n_ref > 1) code_ref_idx(c, cu->ref_idx[sp], E.C->n_ref); code_mvd(c, cu->mvd[sp][0], cu->mvd[sp][1]); cab_bin(c, cu->mvp_idx[sp], CTX_MVP_IDX); }
   }
 }
 FCU_DEV int qt_root_cbf(const CuObj *cu, int part) { return (cu->cbf[0][part] | cu->cbf[1][part] | cu->cbf[2][part]) & 1; }

@@ -216,8 +216,45 @@ int fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *py, const uint
   h.ref_stride[0] = sy; h.ref_stride[1] = h.ref_stride[2] = sc;
   h.ref[0] = py + (size_t)m * sy + m; h.ref[1] = pu + (size_t)(m / 2) * sc + m / 2; h.ref[2] = pv + (size_t)(m / 2) * sc + m / 2;
   static_assert(offsetof(Chain, ref_stride) == offsetof(Chain, ref) + 3 * sizeof(void *), "ref / ref_stride are adjacent");
+  /* one reference picture at POC distance 1 (no vector is ever scaled): list 0 = { this picture } */
+  for (int k = 0; k < 3; k++) h.refs[0][k] = h.ref[k];
+  h.n_ref = 1; h.poc = 1; h.ref_poc[0] = 0; h.col_poc = 0; h.col_ref_poc[0] = -1;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, ref), &h.ref[0], 3 * sizeof(void *) + 3 * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, refs), (const char *)&h + offsetof(Chain, refs), offsetof(Chain, int_mv_r) - offsetof(Chain, refs), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+int fcu_chain_set_references(fcu_ctx *c, int chain, int n_ref, const uint8_t *const *dev_pad_planes, const int *ref_pocs, int cur_poc)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || n_ref < 1 || n_ref > FCU_MAX_REF || !dev_pad_planes || !ref_pocs) return fail(FCU_ERR_ARG, "fcu_chain_set_references: bad argument");
+  for (int k = 0; k < 3 * n_ref; k++) if (!dev_pad_planes[k]) return fail(FCU_ERR_ARG, "fcu_chain_set_references: null plane");
+  for (int a = 0; a < n_ref; a++) { if (ref_pocs[a] == cur_poc) return fail(FCU_ERR_ARG, "fcu_chain_set_references: a reference picture cannot have the current POC");
+    for (int b = 0; b < a; b++) if (ref_pocs[a] == ref_pocs[b]) return fail(FCU_ERR_ARG, "fcu_chain_set_references: the same picture twice in the list"); }
+  int rc = fcu_chain_set_reference(c, chain, dev_pad_planes[0], dev_pad_planes[1], dev_pad_planes[2]);
+  if (rc != FCU_OK) return rc;
+  Chain &h = c->h_chains[(size_t)chain];
+  const int m = FCU_REF_MARGIN, sy = c->sp.width + 2 * m, sc = c->sp.width / 2 + m;
+  for (int r = 0; r < n_ref; r++) {
+    h.refs[r][0] = dev_pad_planes[3 * r] + (size_t)m * sy + m;
+    h.refs[r][1] = dev_pad_planes[3 * r + 1] + (size_t)(m / 2) * sc + m / 2; h.refs[r][2] = dev_pad_planes[3 * r + 2] + (size_t)(m / 2) * sc + m / 2;
+    h.ref_poc[r] = ref_pocs[r];
+  }
+  h.n_ref = n_ref; h.poc = cur_poc; h.col_poc = ref_pocs[0]; h.col_ref_poc[0] = ref_pocs[0] - 1;
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, refs), (const char *)&h + offsetof(Chain, refs), offsetof(Chain, int_mv_r) - offsetof(Chain, refs), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
+int fcu_chain_set_collocated_pocs(fcu_ctx *c, int chain, int col_poc, const int *col_ref_pocs, int n)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !col_ref_pocs || n < 1 || n > FCU_MAX_REF) return fail(FCU_ERR_ARG, "fcu_chain_set_collocated_pocs: bad argument");
+  Chain &h = c->h_chains[(size_t)chain];
+  if (h.out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_collocated_pocs: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  h.col_poc = col_poc;
+  for (int k = 0; k < FCU_MAX_REF; k++) { h.col_ref_poc[k] = k < n ? col_ref_pocs[k] : col_poc - 1; if (h.col_ref_poc[k] == col_poc) return fail(FCU_ERR_ARG, "fcu_chain_set_collocated_pocs: a reference of the collocated picture has its own POC"); }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, refs), (const char *)&h + offsetof(Chain, refs), offsetof(Chain, int_mv_r) - offsetof(Chain, refs), hipMemcpyHostToDevice));
   return FCU_OK;
 }
 

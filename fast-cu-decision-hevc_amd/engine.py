@@ -85,7 +85,9 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_kernel_ms", "fcu_last_error", "fcu_debug_counters", "fcu_chain_set_range", "fcu_obf_prepass", "fcu_chains_per_cu",
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
            "fcu_build_info", "fcu_abi_sizeof", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full",
-           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index", "fcu_chain_set_collocated"]
+           "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index", "fcu_chain_set_collocated",
+           "fcu_chain_set_references", "fcu_chain_set_collocated_pocs"]
+MAX_REF = 4                                                # FCU_MAX_REF: reference pictures in list 0
 
 SLICE_I, SLICE_P = 0, 1
 PUS_PER_CTU = 341
@@ -158,6 +160,8 @@ def load_lib():
     lib.fcu_ldp_layer.argtypes = [C.c_int]
     lib.fcu_chain_set_pu_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.fcu_chain_set_collocated.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.fcu_chain_set_references.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+    lib.fcu_chain_set_collocated_pocs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     _lib = lib
     return lib
 
@@ -260,11 +264,16 @@ class CuEngine:
             raise FcuError(f"{what} failed ({r}): {self.lib.fcu_last_error().decode()}")
 
     # -- TEncCu::init + slice parameters
-    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, ref=None, params=None, col=None, **flags):
+    def init_chain(self, chain, org, qp, slice_ctus=0, rec=None, out=None, ref=None, params=None, col=None,
+                   refs=None, ref_pocs=None, poc=None, col_ref_pocs=None, **flags):
         """org: (Y,U,V) uint8 torch tensors on this device (or numpy arrays, uploaded once).
         params: a FrameParams to start from (e.g. ldp_slice(base_qp, poc)) instead of the I-slice defaults for `qp`;
         ref: padded reference planes from pad_reference() -- required for a P slice;
-        col: the reference picture's fcu_ctu_out array (TMVP, with params.tmvp = 1)."""
+        col: the reference picture's fcu_ctu_out array (TMVP, with params.tmvp = 1);
+        refs / ref_pocs / poc: several reference pictures instead of `ref` -- RefPicList0 as a list of pad_reference() triplets
+        with their POCs and this picture's POC; col_ref_pocs: the POCs the list 0 of refs[0] (the collocated picture) named."""
+        if refs is not None:
+            assert ref is None and 1 <= len(refs) <= MAX_REF and len(ref_pocs) == len(refs) and poc is not None
         torch = self.torch
         dev = torch.device("cuda", self.device)
         planes = []
@@ -292,6 +301,14 @@ class CuEngine:
         if ref is not None:
             self._chk(self.lib.fcu_chain_set_reference(self.h, chain, *[p.data_ptr() for p in ref]), "fcu_chain_set_reference")
             self._keep_ref[chain] = ref
+        if refs is not None:
+            ptrs = (C.c_void_p * (3 * len(refs)))(*[p.data_ptr() for r in refs for p in r])
+            pocs = (C.c_int * len(refs))(*[int(v) for v in ref_pocs])
+            self._chk(self.lib.fcu_chain_set_references(self.h, chain, len(refs), ptrs, pocs, int(poc)), "fcu_chain_set_references")
+            self._keep_ref[chain] = refs
+            if col_ref_pocs:
+                crp = (C.c_int * len(col_ref_pocs))(*[int(v) for v in col_ref_pocs])
+                self._chk(self.lib.fcu_chain_set_collocated_pocs(self.h, chain, int(ref_pocs[0]), crp, len(col_ref_pocs)), "fcu_chain_set_collocated_pocs")
         if col is not None:                                   # TMVP: the reference picture's fcu_ctu_out array (uint8 device tensor)
             assert col.is_cuda and col.numel() >= self.n_ctu * CTU_OUT_BYTES
             self._chk(self.lib.fcu_chain_set_collocated(self.h, chain, col.data_ptr()), "fcu_chain_set_collocated")

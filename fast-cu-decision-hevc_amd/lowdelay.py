@@ -21,12 +21,28 @@ import numpy as np
 
 from . import engine as _engine
 
+HM_LDP_RPS = {1: (-1, -5, -9, -13), 2: (-1, -2, -6, -10), 3: (-1, -3, -7, -11), 0: (-1, -4, -8, -12)}     # reference pictures of Frame1..Frame4 in encoder_lowdelay_P_main.cfg
+
+
+def ref_pocs(poc, n_refs, rps="hm"):
+    """RefPicList0 of picture `poc` (POCs, nearest first).  rps "hm": the reference picture sets of HM's lowdelay_P cfg --
+    the previous picture and the last GOP-boundary pictures -- with the pictures that do not exist yet dropped as the encoder
+    does at the start of a sequence (TEncGOP::selectReferencePictureSet + TComSlice::checkThatAllRefPicsAreAvailable);
+    rps "recent": the last n_refs pictures."""
+    if poc == 0:
+        return []
+    d = HM_LDP_RPS[poc % 4] if rps == "hm" else tuple(-k for k in range(1, n_refs + 1))
+    return [poc + k for k in d if poc + k >= 0][:n_refs]
+
 
 class LowDelayPDecider:
     """`n_clips` clips of width x height decided picture by picture on one GPU.
     slice_ctus: CTUs per slice (HM SliceMode 1); None = one slice per picture (the reference configuration)."""
 
-    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, tmvp=False, fast_search=1, amp=False, device=0):
+    def __init__(self, width, height, base_qp, n_clips=1, search_range=64, slice_ctus=None, deblock=True, sao=False, tmvp=False, fast_search=1, amp=False, device=0,
+                 n_refs=1, rps="hm"):
+        """n_refs: reference pictures in list 0 (the reference cfg's num_ref_idx_active is 4; 1 = the previous picture only);
+        rps: which pictures those are (ref_pocs above)."""
         self.width, self.height, self.base_qp, self.n_clips, self.search_range = width, height, base_qp, n_clips, search_range
         n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
         self.slice_ctus = slice_ctus if slice_ctus else n_ctu
@@ -40,6 +56,9 @@ class LowDelayPDecider:
         self.sao_rate = [_engine.SaoRate() for _ in range(n_clips)]      # m_saoDisabledRate per clip
         self.poc = 0
         self.ref = [None] * n_clips                      # padded reference planes per clip
+        assert 1 <= n_refs <= _engine.MAX_REF and rps in ("hm", "recent")
+        self.n_refs, self.rps = n_refs, rps
+        self.dpb = [dict() for _ in range(n_clips)]      # per clip: poc -> (padded planes, the POCs its list 0 named); pictures a later one may reference
 
     def frame_params(self, poc, cabac_b_table=0):
         fp = _engine.ldp_slice(self.base_qp, poc)
@@ -59,15 +78,19 @@ class LowDelayPDecider:
         assert len(frames) == self.n_clips
         fp = self.frame_params(poc, cabac_b_table)
         res = []
+        rl = ref_pocs(poc, self.n_refs, self.rps)
         for s, f in enumerate(frames):
             first = s * self.n_slices
             ref = self.ref[s] if fp.slice_type == _engine.SLICE_P else None
             col = self.col[s] if fp.tmvp else None
-            rec, out = eng.init_chain(first, f, fp.qp, slice_ctus=self.slice_ctus if self.n_slices > 1 else 0, params=fp, ref=ref, col=col)
+            kw = dict(ref=ref)
+            if ref is not None and self.n_refs > 1:
+                kw = dict(refs=[self.dpb[s][q][0] for q in rl], ref_pocs=rl, poc=poc, col_ref_pocs=self.dpb[s][rl[0]][1])
+            rec, out = eng.init_chain(first, f, fp.qp, slice_ctus=self.slice_ctus if self.n_slices > 1 else 0, params=fp, col=col, **kw)
             planes = eng._keep[first][0]
             for k in range(self.n_slices):
                 if k:
-                    eng.init_chain(first + k, planes, fp.qp, slice_ctus=self.slice_ctus, rec=rec, out=out, params=fp, ref=ref, col=col)
+                    eng.init_chain(first + k, planes, fp.qp, slice_ctus=self.slice_ctus, rec=rec, out=out, params=fp, col=col, **kw)
                 if self.n_slices > 1:
                     a = k * self.slice_ctus
                     eng.set_range(first + k, a, min(self.slice_ctus, eng.n_ctu - a))
@@ -88,6 +111,11 @@ class LowDelayPDecider:
         for s, r in enumerate(res):
             self.col[s] = r["out"]                           # stays in HBM: the next picture's collocated motion field
             self.ref[s] = eng.pad_reference(r["rec"])          # reference of the next picture of this clip
+            if self.n_refs > 1:
+                r["ref_pocs"] = rl
+                self.dpb[s][poc] = (self.ref[s], rl)
+                for q in [q for q in self.dpb[s] if not any(q in ref_pocs(t, self.n_refs, self.rps) for t in range(poc + 1, poc + 17))]:
+                    del self.dpb[s][q]                           # no later picture names it: its planes go back to the allocator
         eng.sync()
         self.poc += 1
         return res

@@ -121,6 +121,15 @@ int  fcu_chain_begin(fcu_ctx *c, int chain, const fcu_frame_params *fp,
  * planes made by fcu_pad_reference (pointers to the first byte of each padded plane; luma stride = width + 2 * 80).
  * Slice QP and lambda of picture `poc` under HM's lowdelay_P GOP table come from fcu_ldp_slice. */
 int  fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *dev_pad_y, const uint8_t *dev_pad_u, const uint8_t *dev_pad_v);
+/* Several reference pictures (HM's lowdelay_P cfg lists four): RefPicList0[r] = dev_pad_planes[3r .. 3r+2] (padded Y, U, V of
+ * fcu_pad_reference) at POC ref_pocs[r], r < n_ref <= FCU_MAX_REF; cur_poc = the picture being decided.  The search then loops
+ * over the reference indices (TEncSearch::predInterSearch, TEncSearch.cpp:3110-3190), codes ref_idx, and scales neighbouring /
+ * collocated vectors that point at another picture by the POC distances (TComDataCU::xGetDistScaleFactor, TComDataCU.cpp:3312).
+ * The collocated picture of TMVP is RefPicList0[0]; name the POCs ITS list 0 referenced with fcu_chain_set_collocated_pocs
+ * (default: one reference at its POC - 1). */
+#define FCU_MAX_REF 4
+int  fcu_chain_set_references(fcu_ctx *c, int chain, int n_ref, const uint8_t *const *dev_pad_planes, const int *ref_pocs, int cur_poc);
+int  fcu_chain_set_collocated_pocs(fcu_ctx *c, int chain, int col_poc, const int *col_ref_pocs, int n);
 /* TMVP: the motion field of the chain's reference picture = the fcu_ctu_out array that picture was decided into (device
  * pointer, fcu_num_ctus() entries, kept alive by the caller).  What TComPic::compressMotion keeps (the top-left 4x4 partition
  * of every 16x16 block) is read in place; frame_params.tmvp switches the temporal candidates on (TComDataCU.cpp:2528-2563,

@@ -43,6 +43,20 @@ void fcu_emu_set_p(void *h, int qp, double lambda, int search_range, int fast_se
   const int m = FCU_REF_MARGIN, sy = width + 2 * m, sc = width / 2 + m;
   e->c.ref_stride[0] = sy; e->c.ref_stride[1] = e->c.ref_stride[2] = sc;
   e->c.ref[0] = py + (size_t)m * sy + m; e->c.ref[1] = pu + (size_t)(m / 2) * sc + m / 2; e->c.ref[2] = pv + (size_t)(m / 2) * sc + m / 2;
+  for (int k = 0; k < 3; k++) e->c.refs[0][k] = e->c.ref[k];
+  e->c.n_ref = 1; e->c.poc = 1; e->c.ref_poc[0] = 0; e->c.col_poc = 0; e->c.col_ref_poc[0] = -1;
+}
+/* several reference pictures: planes[3r .. 3r+2] = padded Y, U, V of RefPicList0[r] (after fcu_emu_set_p with planes[0..2]) */
+void fcu_emu_set_refs(void *h, int n, const uint8_t *const *planes, const int *pocs, int poc, const int *col_ref_pocs, int n_col)
+{
+  EmuChain *e = (EmuChain *)h;
+  const int m = FCU_REF_MARGIN, sy = e->c.p.width + 2 * m, sc = e->c.p.width / 2 + m;
+  for (int r = 0; r < n; r++) {
+    e->c.refs[r][0] = planes[3 * r] + (size_t)m * sy + m; e->c.refs[r][1] = planes[3 * r + 1] + (size_t)(m / 2) * sc + m / 2; e->c.refs[r][2] = planes[3 * r + 2] + (size_t)(m / 2) * sc + m / 2;
+    e->c.ref_poc[r] = pocs[r];
+  }
+  e->c.n_ref = n; e->c.poc = poc; e->c.col_poc = pocs[0];
+  for (int k = 0; k < FCU_MAX_REF; k++) e->c.col_ref_poc[k] = k < n_col ? col_ref_pocs[k] : pocs[0] - 1;
 }
 /* lambda of an I picture that is not the intra_main default (lowdelay_P: 0.57 * 0.85) */
 void fcu_emu_set_lambda(void *h, int qp, double lambda)

@@ -39,8 +39,13 @@ def pad_planes(planes):
 
 
 class EmuEncoder:
-    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1, col=None, amp=0, cabac_b_table=0):
-        """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda)"""
+    def __init__(self, Y, U, V, qp, slice_ctus=0, tools=-1, ref=None, lam=None, search_range=64, fast_search=0, rdoq=1, rdoq_ts=1, col=None, amp=0, cabac_b_table=0,
+                 refs=None, ref_pocs=None, poc=None, col_ref_pocs=None):
+        """ref = (Y, U, V) of the reference picture makes this a P picture (lam = its slice lambda); refs / ref_pocs / poc /
+        col_ref_pocs: several reference pictures, as hmo_py.Encoder takes them"""
+        if refs is not None:
+            assert ref is None and len(refs) == len(ref_pocs) and poc is not None
+            ref = refs[0]
         self.lib = load()
         h, w = Y.shape
         self.org = [np.ascontiguousarray(a, dtype=np.uint8) for a in (Y, U, V)]
@@ -56,6 +61,13 @@ class EmuEncoder:
         if ref is not None:
             self.pad = pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in ref])
             self.lib.fcu_emu_set_p(self.h, qp, float(lam), search_range, fast_search, *[a.ctypes.data for a in self.pad])
+            if refs is not None:
+                self.pads = [pad_planes([np.ascontiguousarray(a, dtype=np.uint8) for a in r]) for r in refs]
+                ptrs = (C.c_void_p * (3 * len(refs)))(*[a.ctypes.data for r in self.pads for a in r])
+                pocs = np.ascontiguousarray(ref_pocs, np.int32)
+                crp = np.ascontiguousarray(col_ref_pocs if col_ref_pocs is not None else [ref_pocs[0] - 1], np.int32)
+                self.lib.fcu_emu_set_refs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+                self.lib.fcu_emu_set_refs(self.h, len(refs), ptrs, pocs.ctypes.data, int(poc), crp.ctypes.data, len(crp))
         elif lam is not None:
             self.lib.fcu_emu_set_lambda(self.h, qp, float(lam))
 

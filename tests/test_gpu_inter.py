@@ -68,6 +68,89 @@ def test_p_pictures_ctu_by_ctu(pkg, gen, w, h, base_qp, n_pic, sr, fast, tmvp, a
     eng.destroy()
 
 
+@pytest.mark.parametrize("case", ["mr2_mixed_qp30", "mr4_textured_qp32", "mr3_amp_shear_qp27"])
+def test_several_reference_pictures(pkg, case):
+    """RefPicList0 with 2..4 pictures (the lowdelay cfg lists four): reference-index loop, ref_idx syntax, POC-scaled spatial and
+    collocated predictors.  The clips are those of tests/golden/inter_mr*.npz, where every candidate of the oracle is checked
+    against the reference's own search; here the HIP engine against the oracle CTU by CTU, and its deblocked pictures against the
+    CRCs of the reference's loop filter."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgi", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    gen, w, h, base_qp, seed, n_pic, sr = m.CASES[case]
+    nref, tmvp, fast, amp = m.MREF[case], m.TMVP.get(case, 0), m.FAST_SEARCH.get(case, 0), m.AMP.get(case, 0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
+    eng = pkg.CuEngine(w, h, max_chains=1)
+    dpb = []                                                    # (poc, deblocked planes, padded device planes, the POCs its list 0 named)
+    prev_out, prev_ctus, n_far = None, None, 0
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
+        fp = pkg.engine.ldp_slice(base_qp, poc)
+        fp.search_range, fp.fast_search, fp.amp, fp.tmvp = sr, fast, amp, 1 if (tmvp and poc) else 0
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        if poc == 0:
+            eng.init_chain(0, f, fp.qp, params=fp)
+            ref = hmo_py.Encoder(*f, qp, lambda_override=lam)
+            pocs = []
+        else:
+            rl = dpb[-nref:][::-1]
+            pocs = [r[0] for r in rl]
+            crp = rl[0][3] or [rl[0][0] - 1]
+            eng.init_chain(0, f, fp.qp, params=fp, refs=[r[2] for r in rl], ref_pocs=pocs, poc=poc, col_ref_pocs=crp, col=prev_out if tmvp else None)
+            ref = hmo_py.Encoder(*f, qp, refs=[r[1] for r in rl], ref_pocs=pocs, poc=poc, col_ref_pocs=crp, col=prev_ctus if tmvp else None,
+                                 lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
+        for a in range(eng.n_ctu):
+            got = eng.compress_ctu(0, a)
+            ref.compress_ctu(a)
+            want = ref.ctu_arrays(a)
+            _same_ctu(got, want, f"{case} poc{poc} ctu{a}")
+            (ce, fe), (co, fo) = eng.ctx_state(0, full=True), ref.cabac(full=True)
+            assert fe == fo and np.array_equal(ce[st.O_SORTED], co[st.O_SORTED]), f"CABAC state poc{poc} ctu{a}"
+            n_far += int(((want["ref_idx"] > 0) & (want["pred_mode"] == 0)).sum())
+        prev_out, prev_ctus = eng._keep[0][2], ref.all_ctus_bytes()
+        assert bytes(prev_out.cpu().numpy()) == prev_ctus
+        eng.deblock(0)
+        eng.sync()
+        planes = [p.copy() for p in eng.rec_planes(0)]
+        if poc:
+            assert [st.crc(p) for p in planes] == [int(v) for v in g[f"deblock_{poc}"][:3]], "deblocked picture vs the reference's own loop filter"
+        dpb.append((poc, planes, eng.pad_reference(eng._keep[0][1]), pocs))
+    assert n_far > 0                                           # partitions predicted from a picture other than the nearest
+    eng.destroy()
+
+
+def test_lowdelay_driver_with_the_cfg_reference_picture_sets(pkg):
+    """LowDelayPDecider with n_refs = 4 and the reference picture sets of HM's lowdelay_P cfg (previous picture + GOP-boundary
+    pictures; pictures 6.. have three references), two slices per picture, TZ + AMP + TMVP: every picture against the oracle
+    run with the same lists."""
+    gen, w, h, base_qp, n_pic, sr, sl = "mixed", 192, 128, 30, 8, 16, 3
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl, fast_search=1, amp=True, tmvp=True, n_refs=4)
+    dpb = {}
+    prev_ctus = None
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, 11, poc)
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        r = dec.decide_picture([f])[0]
+        rl = pkg.lowdelay.ref_pocs(poc, 4)
+        if poc == 0:
+            ref = hmo_py.Encoder(*f, qp, slice_ctus=sl, lambda_override=lam)
+        else:
+            assert r.get("ref_pocs", rl) == rl
+            ref = hmo_py.Encoder(*f, qp, slice_ctus=sl, refs=[dpb[q][0] for q in rl], ref_pocs=rl, poc=poc, col_ref_pocs=dpb[rl[0]][1] or [rl[0] - 1],
+                                 col=prev_ctus, lambda_override=lam, search_range=sr, fast_search=1, amp=1)
+        ref.compress_frame()
+        for a in range(ref.n_ctu):
+            _same_ctu(dec.eng.ctu_out(0, a), ref.ctu_arrays(a), f"poc{poc} ctu{a}")
+        prev_ctus = ref.all_ctus_bytes()
+        ref.deblock()
+        for p, q in zip(r["rec"], ref.rec):
+            assert np.array_equal(p.cpu().numpy(), q), f"deblocked picture poc{poc}"
+        dpb[poc] = ([a.copy() for a in ref.rec], rl)
+    assert len(pkg.lowdelay.ref_pocs(7, 4)) == 3 and len(dec.dpb[0]) <= 4
+    dec.close()
+
+
 def test_ldp_416x240_clip_matches_oracle_and_reference_loop_filter(pkg):
     """The >= 3-picture 416x240 lowdelay_P clip of the golden fixture through the batched driver (one launch per picture)."""
     import importlib.util

@@ -30,6 +30,13 @@ def _tmvp(case):
     return m.TMVP.get(case, 0)
 
 
+def _mref(case):
+    spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.MREF.get(case, 1)
+
+
 def _fast(case):
     spec = importlib.util.spec_from_file_location("make_golden_inter", os.path.join(ROOT, "oracle", "ref", "make_golden_inter.py"))
     m = importlib.util.module_from_spec(spec)
@@ -51,13 +58,16 @@ def dbk_emu(out_arr, rec, w, h, beta=0, tc=0):
 
 
 @pytest.mark.parametrize("case", ["mixed_qp27", "textured_qp37", "tz_mixed_qp27", "tz_textured_qp32", "tmvp_mixed_qp30", "tmvp_textured_qp35",
-                                  "amp_textured_qp27", "amp_mixed_qp30", "amp_shear_qp27"])
+                                  "amp_textured_qp27", "amp_mixed_qp30", "amp_shear_qp27",
+                                  "mr2_mixed_qp30", "mr4_textured_qp32", "mr3_amp_shear_qp27"])     # mr<n>: n reference pictures in list 0
 def test_emulated_engine_p_pictures(case, built, pkg):
     gen, w, h, base_qp, seed, n_pic, sr = _cases()[case]
     g = np.load(os.path.join(ROOT, "tests", "golden", f"inter_{case}.npz"))
     prev = None
     prev_ctus = None
-    n_inter = n_skip = n_amp = 0
+    n_inter = n_skip = n_amp = n_far = 0
+    nref = _mref(case)
+    dpb = []                                                     # (poc, deblocked planes, the POCs its list 0 named)
     for poc in range(n_pic):
         f = st.moving_frame(pkg.synth, gen, w, h, seed, poc)
         _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
@@ -65,8 +75,12 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             o, e = hmo_py.Encoder(*f, qp, lambda_override=lam), emu_py.EmuEncoder(*f, qp, lam=lam)
         else:
             col = prev_ctus if _tmvp(case) else None
-            o = hmo_py.Encoder(*f, qp, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=_fast(case), amp=_amp(case))
-            e = emu_py.EmuEncoder(*f, qp, ref=prev, lam=lam, search_range=sr, fast_search=_fast(case), col=col, amp=_amp(case))
+            kw = dict(ref=prev)
+            if nref > 1:
+                rl = dpb[-nref:][::-1]                           # RefPicList0: most recent first
+                kw = dict(refs=[r[1] for r in rl], ref_pocs=[r[0] for r in rl], poc=poc, col_ref_pocs=rl[0][2] or [rl[0][0] - 1])
+            o = hmo_py.Encoder(*f, qp, col=col, lambda_override=lam, search_range=sr, fast_search=_fast(case), amp=_amp(case), **kw)
+            e = emu_py.EmuEncoder(*f, qp, lam=lam, search_range=sr, fast_search=_fast(case), col=col, amp=_amp(case), **kw)
         for a in range(o.n_ctu):
             o.compress_ctu(a)
             e.compress_ctu(a)
@@ -77,6 +91,7 @@ def test_emulated_engine_p_pictures(case, built, pkg):
             assert fa == fb and np.array_equal(ca[st.O_SORTED], cb[st.O_SORTED]), (poc, a, "CABAC state")
             n_inter += int((A["pred_mode"] == 0).sum())
             n_skip += int(A["skip"].sum())
+            n_far += int(((A["ref_idx"] > 0) & (A["pred_mode"] == 0)).sum())
             n_amp += int(((A["part_size"] >= 4) & (A["part_size"] <= 7) & (A["pred_mode"] == 0)).sum()) if _amp(case) else 0
         for p, q in zip(o.rec, e.rec):
             assert np.array_equal(p, q), (poc, "reconstruction")
@@ -89,7 +104,11 @@ def test_emulated_engine_p_pictures(case, built, pkg):
         for p, q in zip(o.rec, e.rec):
             assert np.array_equal(p, q), (poc, "deblocked picture vs oracle")
         prev = [a.copy() for a in e.rec]
+        dpb.append((poc, prev, kw.get("ref_pocs", [poc - 1]) if poc else []))
     assert n_inter > 0 and n_skip > 0
+    if nref > 1:
+        print("partitions predicted from a picture other than the nearest:", n_far)
+        assert n_far > 0
     if case == "amp_shear_qp27":
         print("partitions of asymmetric CUs:", n_amp)
         assert n_amp > 0                                         # asymmetric partitions survive into the decided pictures
