@@ -134,6 +134,12 @@ template <class T> __device__ inline T fcu_uni(T v)
 #define FCU_FLOOR(x) floor(x)
 #define FCU_CHECK(c) do { } while (0)
 #endif
+/* Squared error of one sample into the distortion word of its candidate `v` (samples i of candidates of n2 samples each, dealt
+ * 64 per iteration).  Blocks of 64 samples or more: the 64 lanes of an iteration share the candidate, so each lane sums in a
+ * register and the wave reduces once per candidate; 4x4 blocks (four candidates per iteration) keep the LDS atomic. */
+#define FCU_DIST_ADD(acc, v, e, i, n2) do { \
+    if ((n2) >= 64) { (acc) += (uint32_t)((e) * (e)); if (((((i) - lane) + 64) & ((n2) - 1)) == 0) { FCU_WAVE_ADD(&g_S.vc_dist[v], acc); (acc) = 0; } } \
+    else FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)((e) * (e))); } while (0)
 #define FCU_SERIAL FCU_FOR_LANES if (lane == 0)
 /* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
 #if defined(FCU_PROFILE) && !defined(FCU_EMU)
@@ -2090,6 +2096,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
   }
   FCU_FOR_LANES {
     by_log2(log2, [&](auto L) {
+      uint32_t acc = 0;
       for (int i = lane; i < nvc * n2; i += 64) {
         const int v = i / n2, p = i - v * n2, cnd = (v >> tss), ts = (v & tss), y = p >> log2, x = p & (N - 1);
         int res = 0;
@@ -2097,7 +2104,7 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_batched(CuObj *cu, uint32_t tu_k)
         const int r = clip8(G->p_pred[cnd * n2 + p] + res);
         G->p_rec[i] = (uint8_t)r;
         const int e = org[y * 64 + x] - r;
-        FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+        FCU_DIST_ADD(acc, v, e, i, n2);
       }
     });
   }
@@ -2236,13 +2243,14 @@ FCU_DEV FCU_NOINLINE void pu_first_pass_64(CuObj *cu, uint32_t root_k)
     FCU_FOR_LANES { by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int i = lane; i < nc * n2; i += 64) { const int v = i / n2; G->p_tcoef[i] = inv1<LG>(rc, G->p_tmp + v * n2, 0, i - v * n2); } }); }
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
+        uint32_t acc = 0;
         for (int i = lane; i < nc * n2; i += 64) {
           const int v = i / n2, p = i - v * n2, y = p >> log2, x = p & (N - 1);
           const int res = g_S.vc_abs[v] > 0 ? inv2<decltype(L)::value>(G->p_tcoef + v * n2, 0, p) : 0;
           const int r = clip8(G->p_pred[i] + res);
           G->c64_rec[v][(tu.y + y) * 64 + tu.x + x] = (uint8_t)r;
           const int e = org[y * 64 + x] - r;
-          FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+          FCU_DIST_ADD(acc, v, e, i, n2);
         }
       });
     }
@@ -2538,6 +2546,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
     }
     FCU_FOR_LANES {
       by_log2(log2, [&](auto L) {
+        uint32_t acc = 0;
         for (int i = lane; i < nvc * n2; i += 64) {
           const int v = i / n2, p = i - v * n2, b = (v >> tss), ts = (v & tss), y = p >> log2, x = p & (N - 1);
           const uint8_t *org = yuv_plane(&G->org[d], comp0 + b / 5) + tu.cy * 32 + tu.cx;
@@ -2546,7 +2555,7 @@ FCU_DEV FCU_NOINLINE void chroma_leaf_trials(CuObj *cu, uint32_t tu_k)
           const int r = clip8(G->p_pred[b * n2 + p] + res);
           G->p_rec[i] = (uint8_t)r;
           const int e = org[y * 32 + x] - r;
-          FCU_ATOMIC_ADD(&g_S.vc_dist[v], (uint32_t)(e * e));
+          FCU_DIST_ADD(acc, v, e, i, n2);
         }
       });
     }

@@ -556,6 +556,7 @@ int fcu_sao(fcu_ctx *c, int n_pics, const fcu_sao_params *params, const uint8_t 
   HIPCHK(hipSetDevice(c->sp.device));
   hipStream_t st = (hipStream_t)hip_stream;
   const int w = c->sp.width, h = c->sp.height, w_ctu = (w + 63) / 64, n_ctu = c->n_ctu;
+  if (w_ctu + 1 > SAO_RING) return fail(FCU_ERR_ARG, "fcu_sao: pictures wider than 255 CTUs are not supported (sao_decide's neighbour ring)");
   const size_t plane[3] = { (size_t)w * h, (size_t)(w / 2) * (h / 2), (size_t)(w / 2) * (h / 2) }, pic_bytes = plane[0] + 2 * plane[1];
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_pics = 0, o_src = up(o_pics + sizeof(SaoPic) * n_pics), o_stats = up(o_src + pic_bytes * n_pics),
@@ -594,7 +595,7 @@ int fcu_sao(fcu_ctx *c, int n_pics, const fcu_sao_params *params, const uint8_t 
   hipLaunchKernelGGL(sao_cands, dim3((unsigned)((n_cand + SAO_THREADS - 1) / SAO_THREADS)), dim3(SAO_THREADS), 0, st, d_pics, d_stats, d_cand, n_ctu, n_pics);
   HIPCHK(hipGetLastError());
   if (kernel_ms4) HIPCHK(hipEventRecord(e[2], st));
-  hipLaunchKernelGGL(sao_decide, dim3((n_pics + 63) / 64), dim3(64), 0, st, d_pics, d_stats, d_cand, dev_coded, d_recon, d_off, w_ctu, n_ctu, n_pics);
+  hipLaunchKernelGGL(sao_decide, dim3(n_pics), dim3(64), 0, st, d_pics, d_stats, d_cand, dev_coded, d_recon, d_off, w_ctu, n_ctu, n_pics);
   HIPCHK(hipGetLastError());
   if (kernel_ms4) HIPCHK(hipEventRecord(e[3], st));
   hipLaunchKernelGGL(sao_apply, dim3(n_ctu, 3, n_pics), dim3(SAO_THREADS), 0, st, d_pics, d_recon, w, h, w_ctu, n_ctu);

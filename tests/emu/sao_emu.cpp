@@ -44,7 +44,8 @@ extern "C" void sao_emu(int w, int h, int slice_type, int qp, int slice_ctus, co
   blockIdx.y = 0;
   for (unsigned b = 0; b < ((unsigned)n_ctu * 15 + SAO_THREADS - 1) / SAO_THREADS; b++)
     for (unsigned t = 0; t < SAO_THREADS; t++) { blockIdx.x = b; threadIdx.x = t; sao_cands_thread(&P, stats.data(), cands.data(), n_ctu, 1); }
-  sao_decide_picture(P, stats.data(), cands.data(), coded, recon.data(), off_count, w_ctu, n_ctu);
+  static SaoDecideLds lds;
+  sao_decide_picture(P, stats.data(), cands.data(), coded, recon.data(), off_count, w_ctu, n_ctu, lds);
   for (unsigned a = 0; a < (unsigned)n_ctu; a++) for (unsigned comp = 0; comp < 3; comp++)
     for (unsigned t = 0; t < SAO_THREADS; t++) { blockIdx.x = a; blockIdx.y = comp; threadIdx.x = t; sao_apply_block(&P, recon.data(), w, h, w_ctu, n_ctu); }
   if (stats_out) memcpy(stats_out, stats.data(), stats.size() * sizeof(int32_t));
