@@ -60,6 +60,10 @@ void ensure_context(const TComSPS *sps)
   FcuState &S = g_fcu;
   const int w = (int)sps->getPicWidthInLumaSamples(), h = (int)sps->getPicHeightInLumaSamples();
   if (S.ctx && S.width == w && S.height == h) return;
+  if (S.ctx) {                                                 /* another picture size: start over */
+    for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_refsrc[c]); for (int k = 0; k < FcuState::N_SLOT; k++) { hipFree(S.d_ref[k][c]); S.ref_valid[k] = false; } }
+    hipFree(S.d_out); hipFree(S.d_out_prev); fcu_destroy(S.ctx); S.ctx = nullptr; S.poc_prev = S.poc_loaded = -1 << 30;
+  }
   if (sps->getChromaFormatIdc() != CHROMA_420 || sps->getBitDepth(CHANNEL_TYPE_LUMA) != 8 || sps->getMaxCUWidth() != 64) { fprintf(stderr, "TEncCuFcu: 8-bit 4:2:0 with 64x64 CTUs only\n"); exit(1); }
   fcu_seq_params sp = { w, h, /*max_chains*/ 1, /*device*/ 0 };
   int rc = fcu_create(&sp, &S.ctx);

@@ -613,6 +613,7 @@ void ref_col_finish_multi(int curPoc, int colPoc, const int *colRefPocs, int n)
   TComSlice *cs = g_refpic->getSlice(0);
   cs->setPOC(colPoc);
   for (int k = 0; k < n; k++) { cs->setRefPOC(colRefPocs[k], REF_PIC_LIST_0, k); cs->setIsUsedAsLongTerm(REF_PIC_LIST_0, k, false); }
+  cs->setSliceType(P_SLICE); cs->setNumRefIdx(REF_PIC_LIST_0, n);     /* (read by the adapter; xGetColMVP asks the CUs, not the slice type) */
   g_slice->setPOC(curPoc); g_slice->setRefPOCList();
   g_slice->setEnableTMVPFlag(true); g_slice->setColFromL0Flag(1); g_slice->setColRefIdx(0); g_slice->setCheckLDC(true);
 }
@@ -637,6 +638,7 @@ void ref_col_finish(int poc)
   g_refpic->compressMotion();
   TComSlice *cs = g_refpic->getSlice(0);
   cs->setPOC(poc - 1); cs->setRefPOC(poc - 2, REF_PIC_LIST_0, 0); cs->setIsUsedAsLongTerm(REF_PIC_LIST_0, 0, false);
+  cs->setSliceType(P_SLICE); cs->setNumRefIdx(REF_PIC_LIST_0, 1);
   g_slice->setPOC(poc); g_slice->setRefPOCList();
   g_slice->setEnableTMVPFlag(true); g_slice->setColFromL0Flag(1); g_slice->setColRefIdx(0); g_slice->setCheckLDC(true);
 }
@@ -784,6 +786,34 @@ void ref_adapter_encode_ctu(int ctu)
   if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); }
   g_cuEnc->m_pcEntropyCoder = g_ent;
   g_cuEnc->encodeCtu(g_pic->getCtu(ctu));
+}
+/* The adapter's TEncCu::compressCtu itself -- device calls included -- on the reference's objects, as TEncSlice::compressSlice
+ * calls it (TEncSlice.cpp:1468): the members TEncCu::init takes from TEncTop are bound to this driver's objects, the slice
+ * carries its lambdas (TEncSlice::setUpLambda -> TComSlice::setLambdas) and the TEncCfg the switches the adapter reads.
+ * Needs a GPU (tests/test_gpu_adapter.py); the decided CTU lands in the picture's TComDataCU and PicYuvRec. */
+int ref_adapter_compress_ctu(int ctu)
+{
+  if (!g_cfg || !g_pic) return -1;
+  if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); }
+  g_cfg->m_sliceMode = NO_SLICES; g_cfg->m_sliceArgument = 0; g_cfg->m_useFastDecisionForMerge = true;
+  g_cuEnc->m_pcEncCfg = g_cfg; g_cuEnc->m_pcRdCost = g_rd; g_cuEnc->m_pcTrQuant = g_trq; g_cuEnc->m_pcEntropyCoder = g_ent;
+  const double l = g_rd->getLambda(), w = g_rd->getChromaWeight();
+  const double ls[3] = { l, l / w, l / w };
+  g_slice->setLambdas(ls);
+  g_cuEnc->compressCtu(g_pic->getCtu(ctu));
+  return 0;
+}
+void ref_adapter_release(void) { if (g_cuEnc) g_cuEnc->destroy(); }
+void ref_set_poc(int poc) { g_slice->setPOC(poc); }
+/* slice lambda of a picture whose lambda is not the all-intra one (TEncSlice::setUpLambda) */
+void ref_set_lambda(double lambda)
+{
+  const int qpc = (int)g_aucChromaScale[CHROMA_420][g_qp];
+  const double w = pow(2.0, (g_qp - qpc) / 3.0);
+  g_rd->setLambda(lambda);
+  g_rd->setDistortionWeight(COMPONENT_Cb, w); g_rd->setDistortionWeight(COMPONENT_Cr, w);
+  double lambdas[3] = { lambda, lambda / w, lambda / w };
+  g_trq->setLambdas(lambdas);
 }
 int ref_adapter_isl_cost(int ctu, int w, int h) { if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); } return g_cuEnc->updateCtuDataISlice(g_pic->getCtu(ctu), w, h); }
 /* planes through the adapter's converters: 8-bit plane -> PicYuvRec block by block (widen_ctu_block), and back (narrow_plane) */

@@ -7,7 +7,7 @@ and through the adapter's TEncCu::encodeCtu into the reference's entropy coder:
     by the reference's coder, driven node by node by make_golden_syntax.py -- an independent walk);
   * P pictures: the reference coder, fed by the adapter, must arrive at the state the oracle's own CTU replay reaches
     (skip / merge / AMVP syntax, inter transform trees) -- which pins that replay through the reference's TEncSbac.
-No GPU: compressCtu itself (device calls) is covered by the compile check adapter/build_check.sh and INTEGRATION.md."""
+No GPU here: compressCtu itself (the device calls) runs in tests/test_gpu_adapter.py, on the same reference objects."""
 import ctypes as C
 import glob
 import os
