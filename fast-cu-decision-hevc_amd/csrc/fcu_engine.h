@@ -65,6 +65,7 @@ template <class T> static inline T fcu_emu_uni(T v, int site, int line)
 #define FCU_FOR_LANES for (int lane = fcu_emu_phase_begin(); lane < 64; lane = fcu_emu_phase_next(lane))
 #define FCU_ATOMIC_ADD(p, v) (*(p) += (v))
 #define FCU_ATOMIC_MAX(p, v) do { if (*(p) < (v)) *(p) = (v); } while (0)
+#define FCU_ATOMIC_OR(p, v) (*(p) |= (v))
 /* wave reductions of per-lane partial results into one LDS word (all 64 lanes call them, outside divergent code) */
 #define FCU_WAVE_ADD(p, v) (*(p) += (v))
 #define FCU_WAVE_MIN64(p, v) do { if ((v) < *(p)) *(p) = (v); } while (0)
@@ -82,6 +83,7 @@ template <class T> static inline T fcu_emu_uni(T v, int site, int line)
 #define FCU_FOR_LANES for (int lane = (int)threadIdx.x, fcu_once_ = 1; fcu_once_; fcu_once_ = 0, __syncthreads())
 #define FCU_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define FCU_ATOMIC_MAX(p, v) atomicMax((p), (v))
+#define FCU_ATOMIC_OR(p, v) atomicOr((p), (v))
 /* wave reductions in registers, then ONE lane touches LDS -- the SAD / SSE / Hadamard partial sums (north star: "wavefront
  * reductions for per-PU costs").  The sum runs on the DPP path of the VALU (six v_add_u32_dpp: two quad permutes, two row
  * rotations, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lane 63 then holds the total) instead of
@@ -144,7 +146,12 @@ template <class T> __device__ inline T fcu_uni(T v)
 /* section timers (diagnostic build only: -DFCU_PROFILE; shader-clock ticks summed per chain by lane 0) */
 #if defined(FCU_PROFILE) && !defined(FCU_EMU)
 #define FCU_TIC(v) const long long v = clock64()
-#ifdef FCU_PROFILE_INTER  /* P-path variant: slots 0..9 and 11..14 belong to the sections of compress_cu's P branch / pred_inter_search (FCU_ITOC); 10 stays the CTU total */
+#ifdef FCU_PROFILE_RQT   /* inter residual quadtree variant: slots 0..8 belong to the stages of inter_tu_trials / est_inter_residual_qt (FCU_QTOC); 10 stays the CTU total */
+#define FCU_QTIC(v) long long v = clock64()
+#define FCU_QTOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); v = clock64(); } while (0)
+#define FCU_TOC(E_, v, idx) do { if ((idx) == 10 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
+#define FCU_COUNT(E_, idx, n) do { } while (0)
+#elif defined(FCU_PROFILE_INTER)  /* P-path variant: slots 0..9 and 11..14 belong to the sections of compress_cu's P branch / pred_inter_search (FCU_ITOC); 10 stays the CTU total */
 #define FCU_ITOC(E_, v, idx) do { if (threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_TOC(E_, v, idx) do { if ((idx) == 10 && threadIdx.x == 0) (E_).C->prof[idx] += (unsigned long long)(clock64() - v); } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
@@ -159,6 +166,10 @@ template <class T> __device__ inline T fcu_uni(T v)
 #define FCU_TIC(v) do { } while (0)
 #define FCU_TOC(E_, v, idx) do { } while (0)
 #define FCU_COUNT(E_, idx, n) do { } while (0)
+#endif
+#ifndef FCU_QTOC
+#define FCU_QTIC(v) do { } while (0)
+#define FCU_QTOC(E_, v, idx) do { } while (0)
 #endif
 #ifndef FCU_ITOC
 #define FCU_ITOC(E_, v, idx) do { } while (0)
@@ -176,7 +187,10 @@ static HotTables g_hot;
 __shared__ HotTables g_hot;
 #endif
 
-#if defined(FCU_PROFILE_RDOQ) && !defined(FCU_EMU)
+#if defined(FCU_PROFILE_RQT) && !defined(FCU_EMU)     /* lane 0 of the lane-private RDOQ (the luma variant of an inter TU): slots 11..15 */
+#define FCU_RTIC(v) long long v = clock64()
+#define FCU_RTOC(P_, v, idx) do { if (!SER && threadIdx.x == 0) { ((Chain *)((char *)&(P_) - __builtin_offsetof(Chain, p)))->prof[idx] += (unsigned long long)(clock64() - v); v = clock64(); } } while (0)
+#elif defined(FCU_PROFILE_RDOQ) && !defined(FCU_EMU)
 #define FCU_RTIC(v) long long v = clock64()
 #define FCU_RTOC(P_, v, idx) do { if (SER) { ((Chain *)((char *)&(P_) - __builtin_offsetof(Chain, p)))->prof[idx] += (unsigned long long)(clock64() - v); v = clock64(); } } while (0)
 #else
@@ -371,6 +385,7 @@ struct Shared {
   int pu_best_vc, pu_best_mode, pu_nvc; uint32_t pu_best_dist; double pu_best_cost;
   /* sequential TU trial mailbox */
   int t_abs, t_lsp, t_last; uint32_t t_dist;
+  int rw_abs, rw_lsp;                               /* rdoq_wave's result */
   /* RQT recursion results */
   double q_cost[4]; uint32_t q_dist[4];
   /* chroma search */
@@ -826,6 +841,120 @@ FCU_DEV FCU_NOINLINE RdoqOut quant_plain(const int32_t *src, int16_t *dst, int s
   return o;
 }
 
+/* The passes of xRateDistOptQuant after its first loop: the last significant position (:2360-2436), the signs, sign bit hiding
+ * (:2442-2572).  Shared by rdoq() and rdoq_wave(); `SER` only names the caller for the diagnostic timers. */
+template <int SER, class CB>
+FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int32_t *srcg, FCU_HBM int16_t *dstg, FCU_HBM RdoqRec *recg, FCU_HBM double *cgg,
+                                       int st, int log2, int ch, int scanType, int cbfCtx, const uint16_t *scan, const uint8_t *scanCG,
+                                       uint64_t cgflag, int cgLastScanPos, int lastScanPos, double baseCost, double blockUncodedCost, double lambda)
+{
+  const int N = 1 << log2;
+  int absSum = 0;
+  FCU_RTIC(rt_);
+
+  double bestCost; int bestLastIdxP1 = 0;
+  bestCost = blockUncodedCost + lambda * (double)cb(cbfCtx, 0);
+  baseCost += lambda * (double)cb(cbfCtx, 1);
+  /* estLastSignificantPositionBit (TEncSbac.cpp:1863-1923) evaluated on demand */
+  const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
+  const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = g_hot.group_idx[N - 1];
+  int foundLast = 0;
+  for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
+    const int cgBlk = scanCG[cgScanPos];
+    baseCost -= cgg[cgScanPos * st];
+    if ((cgflag >> cgBlk) & 1) {
+      const int top = (cgScanPos * 16 + 15 > lastScanPos) ? lastScanPos - cgScanPos * 16 : 15;   /* positions above the last one are skipped */
+      int aLv = dstg[(cgScanPos * 16 + top) * st]; double aCs = recg[(cgScanPos * 16 + top) * st].cs;    /* one ahead */
+      for (int posInCG = top; posInCG >= 0; posInCG--) {
+        const int scanPos = cgScanPos * 16 + posInCG;
+        const int lv = aLv; const double curCs = aCs;
+        if (posInCG > 0) { aLv = dstg[(scanPos - 1) * st]; aCs = recg[(scanPos - 1) * st].cs; }
+        if (lv) {
+          const int blk = scan[scanPos];
+          const int py = blk >> log2, px = blk - (py << log2);
+          const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
+          const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
+          int bxs = 0, bys = 0;
+          for (int k = 0; k < gx; k++) bxs += cb(lbx + (k >> lsh), 1);
+          if (gx < lgmax) bxs += cb(lbx + (gx >> lsh), 0);
+          for (int k = 0; k < gy; k++) bys += cb(lby + (k >> lsh), 1);
+          if (gy < lgmax) bys += cb(lby + (gy >> lsh), 0);
+          double r = (double)(bxs + bys);                                  /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
+          if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
+          if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
+          const double costLast = lambda * r;
+          const double totalCost = baseCost + costLast - curCs;
+          if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
+          if (lv > 1) { foundLast = 1; break; }
+          baseCost -= recg[scanPos * st].cc; baseCost += recg[scanPos * st].c0;
+        } else baseCost -= curCs;
+      }
+      if (foundLast) break;
+    }
+  }
+  FCU_RTOC(P, rt_, 13);                                       /* last-position search */
+  for (int sp0 = 0; sp0 < bestLastIdxP1; sp0 += 16) {           /* signs back on the kept levels, sixteen positions per round of loads */
+    int lv[16]; int32_t sv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int ok = sp0 + k < bestLastIdxP1; lv[k] = ok ? dstg[(sp0 + k) * st] : 0; sv[k] = ok ? srcg[(sp0 + k) * st] : 0; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (sp0 + k < bestLastIdxP1) { absSum += lv[k]; dstg[(sp0 + k) * st] = (int16_t)((sv[k] < 0) ? -lv[k] : lv[k]); }
+  }
+  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
+
+  FCU_RTOC(P, rt_, 14);                                       /* signs */
+  if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
+    const long long rdFactor = P.rd_factor[ch];
+    int lastCG = -1;
+    for (int subSet = (bestLastIdxP1 - 1) >> 4; subSet >= 0; subSet--) {   /* groups above hold no level any more */
+      const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
+      uint32_t nzMask = 0, negMask = 0;                          /* the group's sixteen levels in one go */
+      {
+        int lv16[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) lv16[k] = dstg[(subPos + k) * st];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { sum += lv16[k]; nzMask |= (uint32_t)(lv16[k] != 0) << k; negMask |= (uint32_t)(lv16[k] < 0) << k; }
+      }
+      if (nzMask) { lastNZ = 31 - __builtin_clz(nzMask); firstNZ = __builtin_ctz(nzMask); }
+      if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+      if (lastNZ - firstNZ >= 4) {
+        const uint32_t signbit = (negMask >> firstNZ) & 1;
+        if (signbit != (uint32_t)(sum & 1)) {
+          long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
+          int minPos = -1, finalChange = 0, curChange = 0;
+          for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
+            const int sp = n + subPos; const int lv = dstg[sp * st]; const RdoqRec q = recg[sp * st];
+            if (lv != 0) {
+              const long long costUp = rdFactor * (-q.du) + q.up;
+              long long costDown = rdFactor * (q.du) + q.dn - ((iabs(lv) == 1) ? q.sd : 0);
+              if (lastCG == 1 && lastNZ == n && iabs(lv) == 1) costDown -= (4 << 15);
+              if (costUp < costDown) { curCost = costUp; curChange = 1; }
+              else { curChange = -1; if (n == firstNZ && iabs(lv) == 1) curCost = 0x7fffffffffffffffLL; else curCost = costDown; }
+            } else {
+              curCost = rdFactor * (-(long long)(iabs(q.du))) + (1 << 15) + q.up + q.sd;
+              curChange = 1;
+              if (n < firstNZ) { const uint32_t thissign = srcg[sp * st] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
+            }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = sp; }
+          }
+          const int old = dstg[minPos * st];
+          if (old == 32767 || old == -32768) finalChange = -1;
+          const int nv = srcg[minPos * st] >= 0 ? old + finalChange : old - finalChange;
+          dstg[minPos * st] = (int16_t)nv;
+        }
+      }
+      if (lastCG == 1) lastCG = 0;
+    }
+  }
+  FCU_RTOC(P, rt_, 15);                                       /* sign hiding */
+  int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
+  while (last >= 0 && dstg[last * st] == 0) last--;
+  RdoqOut o = { absSum, last };
+  return o;
+}
+
+
 template <int SER, int EST>
 FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int st, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
 {
@@ -997,107 +1126,239 @@ FCU_DEV FCU_NOINLINE RdoqOut rdoq(int c, const int32_t *src, int16_t *dst, int s
   }
   FCU_RTOC(P, rt_, 12);                                       /* main loop */
   if (lastScanPos < 0) { RdoqOut z = { 0, -1 }; return z; }
+  return rdoq_finish<SER>(cb, P, srcg, dstg, recg, cgg, st, log2, ch, scanType, cbfCtx, scan, scanCG, cgflag, cgLastScanPos, lastScanPos, baseCost, blockUncodedCost, lambda);
+}
 
-  double bestCost; int bestLastIdxP1 = 0;
-  bestCost = blockUncodedCost + lambda * (double)cb(cbfCtx, 0);
-  baseCost += lambda * (double)cb(cbfCtx, 1);
-  /* estLastSignificantPositionBit (TEncSbac.cpp:1863-1923) evaluated on demand */
-  const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
-  const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = g_hot.group_idx[N - 1];
-  int foundLast = 0;
-  for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
-    const int cgBlk = scanCG[cgScanPos];
-    baseCost -= cgg[cgScanPos * st];
-    if ((cgflag >> cgBlk) & 1) {
-      const int top = (cgScanPos * 16 + 15 > lastScanPos) ? lastScanPos - cgScanPos * 16 : 15;   /* positions above the last one are skipped */
-      int aLv = dstg[(cgScanPos * 16 + top) * st]; double aCs = recg[(cgScanPos * 16 + top) * st].cs;    /* one ahead */
-      for (int posInCG = top; posInCG >= 0; posInCG--) {
-        const int scanPos = cgScanPos * 16 + posInCG;
-        const int lv = aLv; const double curCs = aCs;
-        if (posInCG > 0) { aLv = dstg[(scanPos - 1) * st]; aCs = recg[(scanPos - 1) * st].cs; }
-        if (lv) {
-          const int blk = scan[scanPos];
-          const int py = blk >> log2, px = blk - (py << log2);
-          const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
-          const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
-          int bxs = 0, bys = 0;
-          for (int k = 0; k < gx; k++) bxs += cb(lbx + (k >> lsh), 1);
-          if (gx < lgmax) bxs += cb(lbx + (gx >> lsh), 0);
-          for (int k = 0; k < gy; k++) bys += cb(lby + (k >> lsh), 1);
-          if (gy < lgmax) bys += cb(lby + (gy >> lsh), 0);
-          double r = (double)(bxs + bys);                                  /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
-          if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
-          if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
-          const double costLast = lambda * r;
-          const double totalCost = baseCost + costLast - curCs;
-          if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
-          if (lv > 1) { foundLast = 1; break; }
-          baseCost -= recg[scanPos * st].cc; baseCost += recg[scanPos * st].c0;
-        } else baseCost -= curCs;
+/* A value every lane holds one element of, readable and writable by element from wave-uniform code: a register plus
+ * v_readlane / v_writelane on the GPU, an array on the CPU emulator (whose lanes run one after the other). */
+#ifdef FCU_EMU
+template <class T> struct LaneVar {
+  T v[64];
+  LaneVar() { for (int i = 0; i < 64; i++) v[i] = T(); }
+  void set(int lane, T x) { v[lane] = x; }                   /* inside a lane loop: this lane's element */
+  T own(int lane) const { return v[lane]; }
+  T get(int k) const { return v[k]; }                        /* wave-uniform code: element k */
+  void put(int k, T x) { v[k] = x; }
+};
+FCU_DEV uint32_t lane_mask16(const LaneVar<int> &f) { uint32_t m = 0; for (int k = 0; k < 16; k++) m |= (uint32_t)(f.v[k] != 0) << k; return m; }
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FCU_READLANE(v, k) __builtin_amdgcn_readlane((v), (k))
+#define FCU_WRITELANE(val_, k_, old_) (((int)threadIdx.x == (k_)) ? (val_) : (old_))     /* (this compiler has no v_writelane builtin: compare + select) */
+#define FCU_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+#else                                                         /* host pass over the device code: parsed, never run */
+#define FCU_READLANE(v, k) (v)
+#define FCU_WRITELANE(val_, k_, old_) (val_)
+#define FCU_BALLOT(p) ((unsigned long long)(p))
+#endif
+template <class T> struct LaneVar;
+template <> struct LaneVar<int> {
+  int r = 0;
+  __device__ void set(int, int x) { r = x; }
+  __device__ int own(int) const { return r; }
+  __device__ int get(int k) const { return FCU_READLANE(r, k); }
+  __device__ void put(int k, int x) { r = FCU_WRITELANE(x, k, r); }
+};
+template <> struct LaneVar<double> {
+  double r = 0;
+  __device__ void set(int, double x) { r = x; }
+  __device__ double own(int) const { return r; }
+  __device__ double get(int k) const
+  { union { double d; int i[2]; } u; u.d = r; u.i[0] = FCU_READLANE(u.i[0], k); u.i[1] = FCU_READLANE(u.i[1], k); return u.d; }
+  __device__ void put(int k, double x)
+  { union { double d; int i[2]; } u, w; u.d = r; w.d = x; u.i[0] = FCU_WRITELANE(w.i[0], k, u.i[0]); u.i[1] = FCU_WRITELANE(w.i[1], k, u.i[1]); r = u.d; }
+};
+__device__ inline uint32_t lane_mask16(const LaneVar<int> &f) { return (uint32_t)FCU_BALLOT(f.r != 0) & 0xffffu; }
+#endif
+
+/* The same quantiser for ONE block with the whole wave (called from wave-uniform code, not from inside a lane loop): the
+ * un-split trial of a transform unit has a single candidate, and then a lane-private rdoq() leaves 63 lanes idle while one
+ * lane walks every coefficient.  What is serial in xRateDistOptQuant's first loop is the order of the floating-point sums and
+ * the greater1 / greater2 / Rice state, which only a non-zero level moves; everything else about a coefficient -- |level_double|,
+ * uiMaxAbsLevel, its uncoded cost, its significance context and rates, and for a coefficient that can only quantise to 0 the
+ * whole record -- depends on its position and on the group flags of the groups already walked.  So per coefficient group:
+ *   lanes 0..15   one coefficient each, results kept in the lane's registers (LaneVar);
+ *   the wave      the walk in scan order as wave-uniform code: a coefficient's prepared numbers come over v_readlane (no memory
+ *                 access), three additions for one whose uiMaxAbsLevel is 0, the level choice (coded_level) for the others,
+ *                 results back into the owning lane (v_writelane); then the group decisions;
+ *   lanes 0..15   each stores its coefficient's record and level to the pools.
+ * Every floating-point expression and every comparison is the one rdoq() evaluates, in the same order; the passes after the
+ * first loop are rdoq_finish() on lane 0.  st = 1, EST = 1 (the caller has built g_S.est for coder c).
+ * Result: g_S.rw_abs / g_S.rw_lsp. */
+FCU_DEV FCU_NOINLINE void rdoq_wave(int c, const int32_t *src, int16_t *dst, int topNZ, int log2, int comp, int scanType, int cbfCtx, const Params &P_, RdoqRec *rec, double *costCGSig)
+{
+  const Params &P = *FCU_UNI(&P_);
+  c = FCU_UNI(c); src = FCU_UNI(src); dst = FCU_UNI(dst); topNZ = FCU_UNI(topNZ); log2 = FCU_UNI(log2); comp = FCU_UNI(comp);
+  scanType = FCU_UNI(scanType); cbfCtx = FCU_UNI(cbfCtx); rec = FCU_UNI(rec); costCGSig = FCU_UNI(costCGSig);
+  if (topNZ < 0) { FCU_SERIAL { g_S.rw_abs = 0; g_S.rw_lsp = -1; } return; }   /* every level is 0: the reference leaves with uiAbsSum 0 (:2330) */
+  const FCU_HBM int32_t *srcg = (const FCU_HBM int32_t *)src; FCU_HBM int16_t *dstg = (FCU_HBM int16_t *)dst;
+  FCU_HBM RdoqRec *recg = (FCU_HBM RdoqRec *)rec; FCU_HBM double *cgg = (FCU_HBM double *)costCGSig;
+  auto cb = [&](int ctx, int bin) -> int { return (int)FCU_EST[ctx * 2 + bin]; };
+  const int ch = comp ? 1 : 0, N = 1 << log2, n2 = N * N;
+  const int qp = comp ? P.qp_c : P.qp;
+  const int qbits = rdoq_qbits(log2, qp);
+  const double lambda = P.rdoq_lambda[comp];
+  const double errScale = P.err_scale[ch][log2 - 2];
+  const uint16_t *scan = log2 == 2 ? &g_hot.scan[scanType][0] : k_scan + k_scan_off[scanType * 4 + log2 - 2];
+  const uint8_t *scanCG = log2 <= 3 ? g_hot.scan_cg8[log2 == 2 ? 0 : scanType] : k_scan_cg + k_scan_cg_off[scanType * 4 + log2 - 2];
+  const int wg = N >> 2, firstSig = first_sig_ctx(log2, scanType, ch);
+  const int sigOff = CTX_SIG + (ch ? 28 : 0), cgBase = CTX_SIGCG + (ch ? 2 : 0);
+  const uint64_t scan4 = g_hot.scan4_nib[scanType], map4 = g_hot.map4_nib;
+  const int cgTop = topNZ >> 4;
+  /* the walk's state: wave-uniform values (the same in every lane) */
+  uint64_t cgflag = 0;
+  int cgLastScanPos = -1; uint32_t ctxSet = 0; int c1 = 1, c2 = 0;
+  double baseCost = 0, blockUncodedCost = 0;
+  int lastScanPos = -1; uint32_t c1Idx = 0, c2Idx = 0, goRice = 0;
+  int g10 = 0, g10Ctx = -1;
+  /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order); lanes 0..15 load and
+   * square, the wave adds in order */
+  for (int cg = (n2 >> 4) - 1; cg > cgTop; cg--) {
+    LaneVar<double> t0;
+    FCU_FOR_LANES { if (lane < 16) { const double err = (double)iabs(srcg[cg * 16 + lane]); t0.set(lane, err * err * errScale); } }
+    for (int k = 15; k >= 0; k--) blockUncodedCost += t0.get(k);
+  }
+  baseCost = blockUncodedCost;
+  for (int cgScanPos = cgTop; cgScanPos >= 0; cgScanPos--) {
+    const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
+    const int sigBase = sigOff + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
+    const uint32_t cntBits = g_hot.cnt_bits[pattern_sig_ctx(cgflag, cgx, cgy, wg)];
+    LaneVar<int> vLd, vMax, vSb0, vSb1, vUp, vDn, vSd, vDu, vLv, vCand;
+    LaneVar<double> vC0, vCs, vCc;
+    FCU_FOR_LANES {
+      if (lane < 16) {                                         /* one coefficient of this group per lane */
+        const int posInCG = lane, scanPos = cgScanPos * 16 + posInCG;
+        const int32_t levelDouble = iabs(srcg[scanPos]);
+        uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
+        if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
+        const double err = (double)levelDouble;
+        const double c0 = err * err * errScale;
+        const int p4 = (int)((scan4 >> (4 * posInCG)) & 15);
+        int ctxSig;
+        if (log2 == 2) ctxSig = sigOff + (p4 ? (int)((map4 >> (4 * p4)) & 15) : 0);
+        else if (scanPos == 0) ctxSig = sigOff;
+        else ctxSig = sigBase + (int)((cntBits >> (2 * p4)) & 3);
+        const int sbit0 = cb(ctxSig, 0), sbit1 = cb(ctxSig, 1);
+        vLd.set(lane, levelDouble); vMax.set(lane, (int)maxAbsLevel); vSb0.set(lane, sbit0); vSb1.set(lane, sbit1);
+        vC0.set(lane, c0); vCand.set(lane, maxAbsLevel != 0);
+        /* xGetCodedLevel's early exit (:2752-2760) for uiMaxAbsLevel 0: the whole record but rateIncUp, which follows the greater1 state */
+        const double cs = lambda * (double)sbit0;
+        vCs.set(lane, cs); vCc.set(lane, c0 + cs); vSd.set(lane, sbit1 - sbit0); vDu.set(lane, (int32_t)(levelDouble >> (qbits - 8)));
+        vUp.set(lane, 0); vDn.set(lane, 0); vLv.set(lane, 0);
       }
-      if (foundLast) break;
     }
-  }
-  FCU_RTOC(P, rt_, 13);                                       /* last-position search */
-  for (int sp0 = 0; sp0 < bestLastIdxP1; sp0 += 16) {           /* signs back on the kept levels, sixteen positions per round of loads */
-    int lv[16]; int32_t sv[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { const int ok = sp0 + k < bestLastIdxP1; lv[k] = ok ? dstg[(sp0 + k) * st] : 0; sv[k] = ok ? srcg[(sp0 + k) * st] : 0; }
-#pragma unroll
-    for (int k = 0; k < 16; k++) if (sp0 + k < bestLastIdxP1) { absSum += lv[k]; dstg[(sp0 + k) * st] = (int16_t)((sv[k] < 0) ? -lv[k] : lv[k]); }
-  }
-  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
-
-  FCU_RTOC(P, rt_, 14);                                       /* signs */
-  if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
-    const long long rdFactor = P.rd_factor[ch];
-    int lastCG = -1;
-    for (int subSet = (bestLastIdxP1 - 1) >> 4; subSet >= 0; subSet--) {   /* groups above hold no level any more */
-      const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, n;
-      uint32_t nzMask = 0, negMask = 0;                          /* the group's sixteen levels in one go */
-      {
-        int lv16[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) lv16[k] = dstg[(subPos + k) * st];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { sum += lv16[k]; nzMask |= (uint32_t)(lv16[k] != 0) << k; negMask |= (uint32_t)(lv16[k] < 0) << k; }
+    const uint32_t cand = lane_mask16(vCand);
+    double rdSigCost = 0, rdSigCost0 = 0, rdCodedLevelandDist = 0, rdUncodedDist = 0; int nnzBeforePos0 = 0;
+    double cgSig = 0;                                          /* costCGSig of this group */
+    for (int posInCG = 15; posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG;
+      const int isCand = (int)((cand >> posInCG) & 1);
+      double c0 = vC0.get(posInCG), cc = 0, cs = 0;
+      blockUncodedCost += c0;
+      uint32_t level = 0;
+      if (isCand && lastScanPos < 0) {
+        lastScanPos = scanPos;
+        ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && (scanPos >> 4) > 0) ? 2 : 0));
+        cgLastScanPos = cgScanPos;
       }
-      if (nzMask) { lastNZ = 31 - __builtin_clz(nzMask); firstNZ = __builtin_ctz(nzMask); }
-      if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
-      if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = (negMask >> firstNZ) & 1;
-        if (signbit != (uint32_t)(sum & 1)) {
-          long long minCostInc = 0x7fffffffffffffffLL, curCost = 0x7fffffffffffffffLL;
-          int minPos = -1, finalChange = 0, curChange = 0;
-          for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
-            const int sp = n + subPos; const int lv = dstg[sp * st]; const RdoqRec q = recg[sp * st];
-            if (lv != 0) {
-              const long long costUp = rdFactor * (-q.du) + q.up;
-              long long costDown = rdFactor * (q.du) + q.dn - ((iabs(lv) == 1) ? q.sd : 0);
-              if (lastCG == 1 && lastNZ == n && iabs(lv) == 1) costDown -= (4 << 15);
-              if (costUp < costDown) { curCost = costUp; curChange = 1; }
-              else { curChange = -1; if (n == firstNZ && iabs(lv) == 1) curCost = 0x7fffffffffffffffLL; else curCost = costDown; }
-            } else {
-              curCost = rdFactor * (-(long long)(iabs(q.du))) + (1 << 15) + q.up + q.sd;
-              curChange = 1;
-              if (n < firstNZ) { const uint32_t thissign = srcg[sp * st] >= 0 ? 0 : 1; if (thissign != signbit) curCost = 0x7fffffffffffffffLL; }
-            }
-            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = sp; }
-          }
-          const int old = dstg[minPos * st];
-          if (old == 32767 || old == -32768) finalChange = -1;
-          const int nv = srcg[minPos * st] >= 0 ? old + finalChange : old - finalChange;
-          dstg[minPos * st] = (int16_t)nv;
+      if (lastScanPos >= 0) {
+        const int oneCtx = CTX_ONE + 4 * (int)ctxSet + c1;
+        if (oneCtx != g10Ctx) { g10 = cb(oneCtx, 0); g10Ctx = oneCtx; }
+        if (!isCand) {                                         /* level 0 leaves c1/c2/Rice state alone */
+          cs = vCs.get(posInCG); cc = vCc.get(posInCG);
+          vUp.put(posInCG, g10);
+          baseCost += cc;
+          rdSigCost += cs;
+          if (posInCG == 0) rdSigCost0 = cs;
+          continue;
         }
+        const int32_t levelDouble = vLd.get(posInCG); const uint32_t maxAbsLevel = (uint32_t)vMax.get(posInCG);
+        const int sbit0 = vSb0.get(posInCG), sbit1 = vSb1.get(posInCG);
+        auto cbs = [&](int, int bin) -> int { return bin ? sbit1 : sbit0; };   /* the significance rates of this coefficient, looked up by its lane */
+        int sdel = 0, rup, rdn = 0;
+        const int absCtx = CTX_ABS + (int)ctxSet + c2;
+        LevelBits lb; lb.g10 = g10; lb.g11 = cb(oneCtx, 1); lb.g20 = cb(absCtx, 0); lb.g21 = cb(absCtx, 1);
+        int rateHi = 0, rateLo = 0;                            /* xGetICRate(maxAbsLevel), (maxAbsLevel - 1) from the level choice */
+        if (scanPos == lastScanPos)
+          level = coded_level(cbs, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+                              0, lb, goRice, c1Idx, c2Idx, qbits, errScale, 1, &rateHi, &rateLo);
+        else {
+          level = coded_level(cbs, lambda, &cc, &c0, &cs, levelDouble, maxAbsLevel,
+                              0, lb, goRice, c1Idx, c2Idx, qbits, errScale, 0, &rateHi, &rateLo);
+          sdel = sbit1 - sbit0;
+        }
+        if (level > 0) {                                       /* the chosen level is maxAbsLevel or maxAbsLevel - 1: one new rate, not three */
+          if (level == maxAbsLevel) {
+            rup = ic_rate(lb, level + 1, goRice, c1Idx, c2Idx) - rateHi;
+            rdn = (maxAbsLevel > 1 ? rateLo : ic_rate(lb, 0, goRice, c1Idx, c2Idx)) - rateHi;
+          } else {
+            rup = rateHi - rateLo;
+            rdn = ic_rate(lb, level - 1, goRice, c1Idx, c2Idx) - rateLo;
+          }
+        } else rup = lb.g10;
+        vCc.put(posInCG, cc); vCs.put(posInCG, cs); vC0.put(posInCG, c0); vUp.put(posInCG, rup); vDn.put(posInCG, rdn); vSd.put(posInCG, sdel);
+        vDu.put(posInCG, (int32_t)((levelDouble - ((int32_t)level << qbits)) >> (qbits - 8)));
+        baseCost += cc;
+        const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+        if (level >= baseLevel) { if (level > 3u * (1u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4; }
+        if (level >= 1) c1Idx++;
+        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
+        else if (c1 < 3 && c1 > 0 && level) c1++;
+      } else baseCost += c0;
+      vLv.put(posInCG, (int)level);
+      rdSigCost += cs;
+      if (posInCG == 0) rdSigCost0 = cs;
+      if (level) {
+        cgflag |= 1ull << cgBlk;
+        rdCodedLevelandDist += cc - cs;
+        rdUncodedDist += c0;
+        if (posInCG != 0) nnzBeforePos0++;
       }
-      if (lastCG == 1) lastCG = 0;
+    }
+    if (lastScanPos >= 0 && cgScanPos > 0) {                   /* context set of the next group (:2306-2316), once the last position is known */
+      ctxSet = (uint32_t)((ch ? 4 : 0) + ((!ch && (cgScanPos - 1) > 0) ? 2 : 0) + (c1 == 0));
+      c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+    }
+    int zeroed = 0;
+    if (cgLastScanPos >= 0) {
+      if (cgScanPos) {
+        if (((cgflag >> cgBlk) & 1) == 0) {
+          const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
+          baseCost += lambda * (double)cb(ctxSig, 0) - rdSigCost;
+          cgSig = lambda * (double)cb(ctxSig, 0);
+        } else if (cgScanPos < cgLastScanPos) {
+          if (nnzBeforePos0 == 0) { baseCost -= rdSigCost0; rdSigCost -= rdSigCost0; }
+          double costZeroCG = baseCost;
+          const int ctxSig = cgBase + sig_cg_ctx(cgflag, cgx, cgy, wg);
+          baseCost += lambda * (double)cb(ctxSig, 1);
+          costZeroCG += lambda * (double)cb(ctxSig, 0);
+          cgSig = lambda * (double)cb(ctxSig, 1);
+          costZeroCG += rdUncodedDist; costZeroCG -= rdCodedLevelandDist; costZeroCG -= rdSigCost;
+          if (costZeroCG < baseCost) {
+            cgflag &= ~(1ull << cgBlk); baseCost = costZeroCG;
+            cgSig = lambda * (double)cb(ctxSig, 0);
+            zeroed = 1;                                        /* the group's levels go to 0 (applied by their lanes below) */
+          }
+        }
+      } else cgflag |= 1ull << cgBlk;
+    }
+    FCU_FOR_LANES {                                            /* records and levels of the group to the pools */
+      if (lane < 16) {
+        const int sp = cgScanPos * 16 + lane;
+        RdoqRec r; r.cc = vCc.own(lane); r.cs = vCs.own(lane); r.c0 = vC0.own(lane); r.up = vUp.own(lane); r.dn = vDn.own(lane); r.sd = vSd.own(lane); r.du = vDu.own(lane);
+        int lv = vLv.own(lane);
+        if (zeroed && lv) { lv = 0; r.cc = r.c0; r.cs = 0; }
+        recg[sp] = r; dstg[sp] = (int16_t)lv;
+      }
+      if (lane == 0) cgg[cgScanPos] = cgSig;
     }
   }
-  FCU_RTOC(P, rt_, 15);                                       /* sign hiding */
-  int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
-  while (last >= 0 && dstg[last * st] == 0) last--;
-  RdoqOut o = { absSum, last };
-  return o;
+  FCU_SERIAL {
+    RdoqOut o = { 0, -1 };
+    if (lastScanPos >= 0)
+      o = rdoq_finish<0>(cb, P, srcg, dstg, recg, cgg, 1, log2, ch, scanType, cbfCtx, scan, scanCG, cgflag, cgLastScanPos, lastScanPos, baseCost, blockUncodedCost, lambda);
+    g_S.rw_abs = o.abs_sum; g_S.rw_lsp = o.last;
+  }
 }
 
 /* ======================================================================================== */
@@ -1684,19 +1945,21 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
     FCU_FOR_LANES { by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int16_t> rc; for (int i = lane; i < n2; i += 64) G->p_tmp[i] = fwd1<LG>(rc, G->p_resi, useDst, i); }); }
     FCU_FOR_LANES { est_build(cab, lane); by_log2(log2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int i = lane; i < n2; i += 64) { const int sp = iscan[i]; const int32_t ld = level_double(fwd2<LG>(rc, G->p_tmp, useDst, i), qscale, qbits); G->p_lscan[sp] = ld; if (level_nonzero(ld, qbits)) FCU_ATOMIC_MAX(&g_S.t_last, sp); } }); }
   }
-  FCU_FOR_LANES {
-    if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
-    if (lane == 0) {
-      FCU_TIC(t8_);
-      RdoqRec *rrec = G->r_rec; double *rcg = G->r_cg;
-      const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
-      const RdoqOut o = (useTS ? P.rdoq_ts : P.rdoq) ? rdoq<1, 1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, rrec, rcg)
-                                                     : quant_plain(G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, P);
-      g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last;
-      E.C->n_tu_trials++;
-      FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */
-      FCU_TOC(E, t8_, 8);
+  {
+    FCU_TIC(t8_);
+    const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
+    const int useRdoq = FCU_UNI((int)(useTS ? P.rdoq_ts : P.rdoq));
+    if (useRdoq) rdoq_wave(cab, G->p_lscan, G->p_qscan, FCU_UNI(g_S.t_last), log2, comp, scanType, cbfCtx, P, G->r_rec, G->r_cg);
+    FCU_FOR_LANES {
+      if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
+      if (lane == 0) {
+        if (useRdoq) { g_S.t_abs = g_S.rw_abs; g_S.t_lsp = g_S.rw_lsp; }
+        else { const RdoqOut o = quant_plain(G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, P); g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last; }
+        E.C->n_tu_trials++;
+        FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */
+      }
     }
+    FCU_TOC(E, t8_, 8);
   }
   const int absSum = g_S.t_abs;
   FCU_FOR_LANES {                                            /* setCbfPartRange + coefficient store */

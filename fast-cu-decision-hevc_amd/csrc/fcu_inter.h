@@ -875,6 +875,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
   const int btot = NY * NY + (NC ? 2 * NC * NC : 0);
   auto voff = [&](int v) { return (v & 1) ? 1536 + boff[v >> 1] : boff[v >> 1]; };        /* transform-skip variants (4x4 only) live behind the coded ones */
   auto vok = [&](int v) { const int comp = v >> 1; return comp < ncomp && (!(v & 1) || (comp ? tsC : tsY)); };
+  FCU_QTIC(q_);
   FCU_FOR_LANES {                                            /* residual blocks + first transform stage */
     for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)trMode;
     if (lane < 6) { g_S.iv_top[lane] = -1; g_S.acc[lane] = 0; g_S.acc[6 + (lane >> 1)] = 0; }
@@ -907,9 +908,20 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       else by_log2(l2, [&](auto L) { constexpr int LG = decltype(L)::value; RowCache<(1 << LG), int32_t> rc; for (int k = lane; k < n2; k += 64) put(k, fwd2<LG>(rc, G->p_tmp + boff[comp], 0, k)); });
     }
   }
-  /* RDOQ: one variant per lane, all priced against the snapshot.  rdoq() and code_coeff_nxn() take block size and
-   * channel type as wave-uniform (scalar) arguments, so the luma variants and the chroma variants go in two rounds */
+  FCU_QTOC(E, q_, 0);
+  /* RDOQ, all variants priced against the snapshot.  Blocks of 8x8 and more (they have no transform-skip variant): one after
+   * the other with the whole wave (rdoq_wave); 4x4 blocks: one variant per lane -- rdoq() and code_coeff_nxn() take block size
+   * and channel type as wave-uniform (scalar) arguments, so the luma variants and the chroma variants go in two rounds */
+  const int waveY = FCU_UNI((int)(log2 >= 3 && P.rdoq)), waveC = FCU_UNI((int)(NC && lc >= 3 && P.rdoq));
+  for (int v = 0; v < 6; v += 2) {
+    const int comp = v >> 1;
+    if (!(comp ? waveC : waveY) || comp >= ncomp) continue;
+    const int cbfCtx = (comp == 0 && trMode == 0) ? EST_ROOT_CBF : qt_cbf_ctx(tu, comp);      /* blockRootCbpBits, TComTrQuant.cpp:2358 */
+    rdoq_wave(CAB_GOON, G->p_lscan + voff(v), G->p_qscan + voff(v), FCU_UNI(g_S.iv_top[v]), bl2[comp], comp ? 1 : 0, 0, cbfCtx, P, G->r_rec + voff(v), G->r_cg + v * 64);
+    FCU_SERIAL { g_S.iv_abs[v] = g_S.rw_abs; g_S.iv_lsp[v] = g_S.rw_lsp; }
+  }
   for (int ch = 0; ch < (NC ? 2 : 1); ch++) {
+    if (ch ? waveC : waveY) continue;
     FCU_FOR_LANES {
       if (lane < 6 && vok(lane) && ((lane >> 1) != 0) == (ch != 0)) {
         const int comp = lane >> 1, l2 = bl2[comp], o = voff(lane);
@@ -919,9 +931,10 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
           : quant_plain(G->p_lscan + o, G->p_qscan + o, 1, g_S.iv_top[lane], l2, comp ? 1 : 0, P);
         g_S.iv_abs[lane] = r.abs_sum; g_S.iv_lsp[lane] = r.last;
       }
-      if (lane == 0 && ch == 0) E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0));
     }
   }
+  FCU_SERIAL { E.C->n_tu_trials += (unsigned long long)(ncomp + (tsY ? 1 : 0) + (tsC ? 2 : 0)); }
+  FCU_QTOC(E, q_, 1);
   FCU_FOR_LANES {                                            /* dequantisation (transposed for the inverse stages) */
     for (int v = 0; v < 6; v++) {
       if (!vok(v) || g_S.iv_abs[v] <= 0) continue;
@@ -956,6 +969,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       FCU_WAVE_ADD(&g_S.acc[v], sse);
     }
   }
+  FCU_QTOC(E, q_, 2);
   for (int ch = 0; ch < (NC ? 2 : 1); ch++) {                  /* bits of (cbf, coefficients) per variant on lane-private coders */
     FCU_FOR_LANES {
       if (lane < 6 && vok(lane) && ((lane >> 1) != 0) == (ch != 0) && g_S.iv_abs[lane] > 0) {
@@ -967,6 +981,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       }
     }
   }
+  FCU_QTOC(E, q_, 3);
   FCU_SERIAL {                                               /* per component: coded / skipped / transform-skip (TEncSearch.cpp:4640-4900) */
     const uint64_t low = g_S.cab[CAB_GOON].frac & 32767;
     for (int comp = 0; comp < ncomp; comp++) {
@@ -1005,6 +1020,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
       for (int i = lane; i < cnp; i += 64) { cu->tskip[comp][cpart + i] = (uint8_t)g_S.it_ts[comp]; cu->cbf[comp][cpart + i] = (uint8_t)((coded ? 1 : 0) << trMode); }
     }
   }
+  FCU_QTOC(E, q_, 4);
   FCU_SERIAL {                                               /* syntax of the whole TU from the snapshot: subdivision flag, cbf Cb Cr Y, coefficients Y Cb Cr */
     const int c = CAB_GOON;
     cab_reset_bits(c);
@@ -1018,6 +1034,7 @@ FCU_DEV FCU_NOINLINE void inter_tu_trials(CuObj *cu, uint32_t tu_k, int addZero)
     }
     g_S.iv_bits[0] = cab_bits(c); g_S.iv_dist[0] = dist;
   }
+  FCU_QTOC(E, q_, 5);
   (void)depth;
 }
 
@@ -1052,12 +1069,14 @@ FCU_DEV FCU_NOINLINE void est_inter_residual_qt(CuObj *cu, uint32_t tu_k, int ad
         g_S.uni[3] = any;
       }
       FCU_FOR_LANES { for (int c = 0; c < 3; c++) for (int o = lane; o < 4 * q; o += 64) cu->cbf[c][part + o] |= (uint8_t)(g_S.uni[c] << trMode); cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, depth, CI_QT_TRAFO_ROOT), lane); }
+      { FCU_QTIC(q6_);
       FCU_SERIAL {
         cab_reset_bits(CAB_GOON);
         encode_inter_residual_qt(CAB_GOON, cu, tu_key(tu), 3);
         for (int c = 0; c < 3; c++) encode_inter_residual_qt(CAB_GOON, cu, tu_key(tu), c);
         g_S.iv_bits[1] = cab_bits(CAB_GOON);
       }
+      FCU_QTOC(E, q6_, 6); }
       const uint32_t subBits = FCU_UNI(g_S.iv_bits[1]), subDist = FCU_UNI(g_S.iq_dist[LEVEL + 1]);
       const double subCost = rd_cost(P, subBits, subDist);
       const int cbfAny = FCU_UNI(g_S.uni[3]);
@@ -1167,7 +1186,7 @@ FCU_DEV FCU_NOINLINE void encode_res_and_calc_rd_inter_cu(CuObj *cu, int skipRes
     if (lane == 0) { g_S.iq_cost[0] = 0; g_S.iq_bits[0] = 0; g_S.iq_dist[0] = 0; g_S.iq_zero = 0; }
   }
   TU root; tu_root(root, d);
-  est_inter_residual_qt<0>(cu, tu_key(root), 1);
+  { FCU_QTIC(q8_); est_inter_residual_qt<0>(cu, tu_key(root), 1); FCU_QTOC(E, q8_, 8); }
   FCU_SERIAL {
     cab_reset_bits(CAB_GOON); cab_bin(CAB_GOON, 0, CTX_ROOT_CBF);                            /* encodeQtRootCbfZero */
     const double zeroCost = rd_cost(P, cab_bits(CAB_GOON), g_S.iq_zero);
@@ -1181,7 +1200,7 @@ FCU_DEV FCU_NOINLINE void encode_res_and_calc_rd_inter_cu(CuObj *cu, int skipRes
     cab_copy(&g_S.cab[CAB_GOON], slot_ptr(E, d, CI_CURR_BEST), lane);
     if (cu->merge_flag[0] && cu->part_size[0] == SIZE_2Nx2N && zeroOut) for (int i = lane; i < n; i += 64) cu->skip[i] = 1;   /* xAddSymbolBitsInter */
   }
-  FCU_SERIAL { cab_reset_bits(CAB_GOON); encode_cu_syntax_inter(E, CAB_GOON, cu, 0, d); cu->bits = cab_bits(CAB_GOON); }
+  { FCU_QTIC(q7_); FCU_SERIAL { cab_reset_bits(CAB_GOON); encode_cu_syntax_inter(E, CAB_GOON, cu, 0, d); cu->bits = cab_bits(CAB_GOON); } FCU_QTOC(E, q7_, 7); }
   if (!zeroOut && hit < 0) set_inter_residual_qt_data(cu, 1);
   if (hit < 0) {                                             /* memo store: next slot of this depth */
     const int k = FCU_UNI(G->memo_next[d]);
