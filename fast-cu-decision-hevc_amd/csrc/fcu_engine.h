@@ -841,17 +841,14 @@ FCU_DEV FCU_NOINLINE RdoqOut quant_plain(const int32_t *src, int16_t *dst, int s
   return o;
 }
 
-/* The passes of xRateDistOptQuant after its first loop: the last significant position (:2360-2436), the signs, sign bit hiding
- * (:2442-2572).  Shared by rdoq() and rdoq_wave(); `SER` only names the caller for the diagnostic timers. */
-template <int SER, class CB>
-FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int32_t *srcg, FCU_HBM int16_t *dstg, FCU_HBM RdoqRec *recg, FCU_HBM double *cgg,
-                                       int st, int log2, int ch, int scanType, int cbfCtx, const uint16_t *scan, const uint8_t *scanCG,
-                                       uint64_t cgflag, int cgLastScanPos, int lastScanPos, double baseCost, double blockUncodedCost, double lambda)
+/* The passes of xRateDistOptQuant after its first loop, shared by rdoq() and rdoq_wave(): the last significant position
+ * (:2360-2436), the signs, sign bit hiding (:2442-2572). */
+template <class CB>
+FCU_DEV FCU_INLINE int rdoq_last_pos(CB cb, const FCU_HBM int16_t *dstg, const FCU_HBM RdoqRec *recg, const FCU_HBM double *cgg,
+                                     int st, int log2, int ch, int scanType, int cbfCtx, const uint16_t *scan, const uint8_t *scanCG,
+                                     uint64_t cgflag, int cgLastScanPos, int lastScanPos, double baseCost, double blockUncodedCost, double lambda)
 {
   const int N = 1 << log2;
-  int absSum = 0;
-  FCU_RTIC(rt_);
-
   double bestCost; int bestLastIdxP1 = 0;
   bestCost = blockUncodedCost + lambda * (double)cb(cbfCtx, 0);
   baseCost += lambda * (double)cb(cbfCtx, 1);
@@ -892,7 +889,12 @@ FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int
       if (foundLast) break;
     }
   }
-  FCU_RTOC(P, rt_, 13);                                       /* last-position search */
+  return bestLastIdxP1;
+}
+/* signs back on the kept levels, zeros above the chosen last position; returns uiAbsSum */
+FCU_DEV FCU_INLINE int rdoq_signs(const FCU_HBM int32_t *srcg, FCU_HBM int16_t *dstg, int st, int bestLastIdxP1, int lastScanPos)
+{
+  int absSum = 0;
   for (int sp0 = 0; sp0 < bestLastIdxP1; sp0 += 16) {           /* signs back on the kept levels, sixteen positions per round of loads */
     int lv[16]; int32_t sv[16];
 #pragma unroll
@@ -902,7 +904,10 @@ FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int
   }
   for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dstg[sp * st] = 0;
 
-  FCU_RTOC(P, rt_, 14);                                       /* signs */
+  return absSum;
+}
+FCU_DEV FCU_INLINE void rdoq_sign_hiding(const Params &P, const FCU_HBM int32_t *srcg, FCU_HBM int16_t *dstg, const FCU_HBM RdoqRec *recg, int st, int ch, int bestLastIdxP1, int absSum)
+{
   if (P.sign_hiding && absSum >= 2) {                        /* TComTrQuant.cpp:2442-2572 */
     const long long rdFactor = P.rd_factor[ch];
     int lastCG = -1;
@@ -947,6 +952,18 @@ FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int
       if (lastCG == 1) lastCG = 0;
     }
   }
+}
+template <int SER, class CB>
+FCU_DEV FCU_INLINE RdoqOut rdoq_finish(CB cb, const Params &P, const FCU_HBM int32_t *srcg, FCU_HBM int16_t *dstg, FCU_HBM RdoqRec *recg, FCU_HBM double *cgg,
+                                       int st, int log2, int ch, int scanType, int cbfCtx, const uint16_t *scan, const uint8_t *scanCG,
+                                       uint64_t cgflag, int cgLastScanPos, int lastScanPos, double baseCost, double blockUncodedCost, double lambda)
+{
+  FCU_RTIC(rt_);
+  const int bestLastIdxP1 = rdoq_last_pos(cb, dstg, recg, cgg, st, log2, ch, scanType, cbfCtx, scan, scanCG, cgflag, cgLastScanPos, lastScanPos, baseCost, blockUncodedCost, lambda);
+  FCU_RTOC(P, rt_, 13);                                       /* last-position search */
+  const int absSum = rdoq_signs(srcg, dstg, st, bestLastIdxP1, lastScanPos);
+  FCU_RTOC(P, rt_, 14);                                       /* signs */
+  rdoq_sign_hiding(P, srcg, dstg, recg, st, ch, bestLastIdxP1, absSum);
   FCU_RTOC(P, rt_, 15);                                       /* sign hiding */
   int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
   while (last >= 0 && dstg[last * st] == 0) last--;
@@ -1213,14 +1230,20 @@ FCU_DEV FCU_NOINLINE void rdoq_wave(int c, const int32_t *src, int16_t *dst, int
   int g10 = 0, g10Ctx = -1;
   /* coefficient groups above the last candidate level: only the uncoded cost accumulates (in scan order); lanes 0..15 load and
    * square, the wave adds in order */
-  for (int cg = (n2 >> 4) - 1; cg > cgTop; cg--) {
+  for (int cg = (n2 >> 4) - 1; cg > cgTop; cg -= 4) {           /* four groups per round of loads: lanes 16 j .. 16 j + 15 take group cg - j */
     LaneVar<double> t0;
-    FCU_FOR_LANES { if (lane < 16) { const double err = (double)iabs(srcg[cg * 16 + lane]); t0.set(lane, err * err * errScale); } }
-    for (int k = 15; k >= 0; k--) blockUncodedCost += t0.get(k);
+    FCU_FOR_LANES { const int g = cg - (lane >> 4); if (g > cgTop) { const double err = (double)iabs(srcg[g * 16 + (lane & 15)]); t0.set(lane, err * err * errScale); } }
+    for (int j = 0; j < 4 && cg - j > cgTop; j++)
+      for (int k = 15; k >= 0; k--) blockUncodedCost += t0.get(j * 16 + k);
   }
   baseCost = blockUncodedCost;
+  /* memory latency off the walk: lane k holds the block position of group k for the whole call, and a group's coefficients are
+   * fetched while the group before it is walked */
+  LaneVar<int> vCgBlk, vNext;
+  LaneVar<double> vCgSig;                                      /* costCGSig of group k in lane k (also stored to the pool) */
+  FCU_FOR_LANES { if (lane <= cgTop) vCgBlk.set(lane, scanCG[lane]); if (lane < 16) vNext.set(lane, srcg[cgTop * 16 + lane]); }
   for (int cgScanPos = cgTop; cgScanPos >= 0; cgScanPos--) {
-    const int cgBlk = scanCG[cgScanPos], cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
+    const int cgBlk = vCgBlk.get(cgScanPos), cgy = cgBlk / wg, cgx = cgBlk - cgy * wg;
     const int sigBase = sigOff + firstSig + ((!ch && (cgx + cgy) > 0) ? 3 : 0);
     const uint32_t cntBits = g_hot.cnt_bits[pattern_sig_ctx(cgflag, cgx, cgy, wg)];
     LaneVar<int> vLd, vMax, vSb0, vSb1, vUp, vDn, vSd, vDu, vLv, vCand;
@@ -1228,7 +1251,8 @@ FCU_DEV FCU_NOINLINE void rdoq_wave(int c, const int32_t *src, int16_t *dst, int
     FCU_FOR_LANES {
       if (lane < 16) {                                         /* one coefficient of this group per lane */
         const int posInCG = lane, scanPos = cgScanPos * 16 + posInCG;
-        const int32_t levelDouble = iabs(srcg[scanPos]);
+        const int32_t levelDouble = iabs(vNext.own(lane));
+        if (cgScanPos > 0) vNext.set(lane, srcg[scanPos - 16]);
         uint32_t maxAbsLevel = (uint32_t)((levelDouble + ((int32_t)1 << (qbits - 1))) >> qbits);
         if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
         const double err = (double)levelDouble;
@@ -1352,12 +1376,76 @@ FCU_DEV FCU_NOINLINE void rdoq_wave(int c, const int32_t *src, int16_t *dst, int
       }
       if (lane == 0) cgg[cgScanPos] = cgSig;
     }
+    vCgSig.put(cgScanPos, cgSig);
+  }
+  if (lastScanPos < 0) { FCU_SERIAL { g_S.rw_abs = 0; g_S.rw_lsp = -1; } return; }
+  /* rdoq_last_pos as a wave: per group that kept a level, lanes fetch level and record of a position each and price it as the
+   * last one (xGetRateLast); the walk over the positions -- the running cost without the coefficients above -- is wave-uniform
+   * code on those numbers, same expressions in the same order */
+  int bestLastIdxP1 = 0;
+  {
+    double bestCost = blockUncodedCost + lambda * (double)cb(cbfCtx, 0);
+    baseCost += lambda * (double)cb(cbfCtx, 1);
+    const int lcc = log2 - 2, loff = ch ? 0 : (lcc * 3 + ((lcc + 1) >> 2)), lsh = ch ? lcc : ((lcc + 3) >> 2);
+    const int lbx = CTX_LASTX + (ch ? 15 : 0) + loff, lby = CTX_LASTY + (ch ? 15 : 0) + loff, lgmax = g_hot.group_idx[N - 1];
+    int foundLast = 0;
+    for (int cgScanPos = cgLastScanPos; cgScanPos >= 0 && !foundLast; cgScanPos--) {
+      const int cgBlk = vCgBlk.get(cgScanPos);
+      baseCost -= vCgSig.get(cgScanPos);
+      if (!((cgflag >> cgBlk) & 1)) continue;
+      const int top = (cgScanPos * 16 + 15 > lastScanPos) ? lastScanPos - cgScanPos * 16 : 15;   /* positions above the last one are skipped */
+      LaneVar<int> wLv; LaneVar<double> wCs, wCc, wC0, wCl;
+      FCU_FOR_LANES {
+        if (lane <= top) {
+          const int scanPos = cgScanPos * 16 + lane;
+          const int lv = dstg[scanPos];
+          const RdoqRec q = recg[scanPos];
+          wLv.set(lane, lv); wCs.set(lane, q.cs); wCc.set(lane, q.cc); wC0.set(lane, q.c0);
+          double costLast = 0;
+          if (lv) {
+            const int blk = scan[scanPos];
+            const int py = blk >> log2, px = blk - (py << log2);
+            const int ax = scanType == 2 ? py : px, ay = scanType == 2 ? px : py;
+            const int gx = g_hot.group_idx[ax], gy = g_hot.group_idx[ay];
+            int bxs = 0, bys = 0;
+            for (int k = 0; k < gx; k++) bxs += cb(lbx + (k >> lsh), 1);
+            if (gx < lgmax) bxs += cb(lbx + (gx >> lsh), 0);
+            for (int k = 0; k < gy; k++) bys += cb(lby + (k >> lsh), 1);
+            if (gy < lgmax) bys += cb(lby + (gy >> lsh), 0);
+            double r = (double)(bxs + bys);                                  /* xGetRateLast, TComTrQuant.cpp:2898-2916 */
+            if (gx > 3) r += 32768.0 * (double)((gx - 2) >> 1);
+            if (gy > 3) r += 32768.0 * (double)((gy - 2) >> 1);
+            costLast = lambda * r;
+          }
+          wCl.set(lane, costLast);
+        }
+      }
+      for (int posInCG = top; posInCG >= 0; posInCG--) {
+        const int lv = wLv.get(posInCG); const double curCs = wCs.get(posInCG);
+        if (lv) {
+          const double totalCost = baseCost + wCl.get(posInCG) - curCs;
+          if (totalCost < bestCost) { bestLastIdxP1 = cgScanPos * 16 + posInCG + 1; bestCost = totalCost; }
+          if (lv > 1) { foundLast = 1; break; }
+          baseCost -= wCc.get(posInCG); baseCost += wC0.get(posInCG);
+        } else baseCost -= curCs;
+      }
+    }
+  }
+  FCU_SERIAL { g_S.rw_abs = 0; }
+  FCU_FOR_LANES {                                              /* rdoq_signs with a position per lane */
+    uint32_t acc = 0;
+    for (int sp = lane; sp <= lastScanPos; sp += 64) {
+      if (sp < bestLastIdxP1) { const int lv = dstg[sp]; acc += (uint32_t)lv; dstg[sp] = (int16_t)((srcg[sp] < 0) ? -lv : lv); }
+      else dstg[sp] = 0;
+    }
+    FCU_WAVE_ADD((uint32_t *)&g_S.rw_abs, acc);
   }
   FCU_SERIAL {
-    RdoqOut o = { 0, -1 };
-    if (lastScanPos >= 0)
-      o = rdoq_finish<0>(cb, P, srcg, dstg, recg, cgg, 1, log2, ch, scanType, cbfCtx, scan, scanCG, cgflag, cgLastScanPos, lastScanPos, baseCost, blockUncodedCost, lambda);
-    g_S.rw_abs = o.abs_sum; g_S.rw_lsp = o.last;
+    const int absSum = g_S.rw_abs;
+    rdoq_sign_hiding(P, srcg, dstg, recg, 1, ch, bestLastIdxP1, absSum);
+    int last = bestLastIdxP1 - 1;                              /* sign hiding may have cleared the last level */
+    while (last >= 0 && dstg[last] == 0) last--;
+    g_S.rw_lsp = last;
   }
 }
 
