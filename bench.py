@@ -140,6 +140,8 @@ def parse_args(argv=None):
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--fast-search", type=int, default=1, help="lowdelay_P integer motion search: 1 = TZ search (FastSearch 1, the reference cfg's setting), 0 = full search")
     ap.add_argument("--amp", type=int, default=0, help="lowdelay_P: 1 = asymmetric motion partitions (AMP 1 of the reference cfg)")
+    ap.add_argument("--refs", type=int, default=1, help="lowdelay_P: reference pictures in list 0 (1..4; the reference cfg's num_ref_idx_active is 4): pictures 0..refs-1 "
+                    "are decided untimed, picture `refs` is timed with the `refs` pictures before it as RefPicList0, most recent first")
     ap.add_argument("--shear", type=int, default=0, help="lowdelay_P: 1 = clips with motion boundaries inside the CUs (bands moving with a second vector) instead of one global motion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the chain-count sweep and the transfer measurement")
@@ -204,29 +206,36 @@ def run(args, emit=True):
 
     frames, recs, outs, refs, fps = {}, {}, {}, {}, {}
     for seed in seeds:
-        frames[seed] = gen_moving_gpu(torch, dev, W, H, seed, 1 if ldp else 0, shear=args.shear) if ldp else gen_textured_gpu(torch, dev, W, H, seed)
+        frames[seed] = gen_moving_gpu(torch, dev, W, H, seed, args.refs if ldp else 0, shear=args.shear) if ldp else gen_textured_gpu(torch, dev, W, H, seed)
     for seed in seeds:
         for qp in qps:
             recs[(seed, qp)] = [torch.zeros_like(p) for p in frames[seed]]
             outs[(seed, qp)] = torch.zeros(nb * n_ctu, dtype=torch.uint8, device=dev)
 
     if ldp:
-        # untimed: picture 0 of every clip (intra, same slice structure), loop filter, padding -> the reference pictures
-        fp0 = pkg.engine.ldp_slice(32, 0)
-        pic0 = {seed: gen_moving_gpu(torch, dev, W, H, seed, 0, shear=args.shear) for seed in seeds}
-        for ci, (seed, qp, k) in enumerate(chain_list):
-            eng.init_chain(ci, pic0[seed], fp0.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp0)
-            if n_sl > 1:
-                eng.set_range(ci, k * sl, min(sl, n_ctu - k * sl))
-        eng.compress_chains(0, n_chains, sl)
-        for seed in seeds:
-            eng.deblock(out=outs[(seed, 32)], rec=recs[(seed, 32)])
-            refs[seed] = eng.pad_reference(recs[(seed, 32)])
-            recs[(seed, 32)] = [torch.zeros_like(p) for p in frames[seed]]
-        eng.sync()
-        pic0_host = [p.cpu().numpy() for p in pic0[seeds[0]]] if rank == 0 else None
-        del pic0
-        fp1 = pkg.engine.ldp_slice(32, 1)
+        # untimed: pictures 0 .. refs-1 of every clip (picture 0 intra, the others P on the pictures before them; same slice
+        # structure), loop filter, padding -> the reference pictures of the timed picture `refs`, most recent first
+        assert 1 <= args.refs <= 4
+        pads = {seed: [] for seed in seeds}
+        for poc in range(args.refs):
+            fpp = pkg.engine.ldp_slice(32, poc)
+            fpp.search_range, fpp.fast_search, fpp.amp = args.search_range, args.fast_search, args.amp
+            pics = {seed: gen_moving_gpu(torch, dev, W, H, seed, poc, shear=args.shear) for seed in seeds}
+            for ci, (seed, qp, k) in enumerate(chain_list):
+                kw = {} if poc == 0 else (dict(ref=pads[seed][0]) if poc == 1 else dict(refs=list(pads[seed]), ref_pocs=list(range(poc - 1, -1, -1)), poc=poc))
+                eng.init_chain(ci, pics[seed], fpp.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fpp, **kw)
+                if n_sl > 1:
+                    eng.set_range(ci, k * sl, min(sl, n_ctu - k * sl))
+            eng.compress_chains(0, n_chains, sl)
+            for seed in seeds:
+                eng.deblock(out=outs[(seed, 32)], rec=recs[(seed, 32)])
+                pads[seed].insert(0, eng.pad_reference(recs[(seed, 32)]))
+                recs[(seed, 32)] = [torch.zeros_like(p) for p in frames[seed]]
+            eng.sync()
+            del pics
+        refs = {seed: pads[seed][0] for seed in seeds}
+        ref_pocs = list(range(args.refs - 1, -1, -1))
+        fp1 = pkg.engine.ldp_slice(32, args.refs)
         fp1.search_range = args.search_range
         fp1.fast_search = args.fast_search
         fp1.amp = args.amp
@@ -234,7 +243,8 @@ def run(args, emit=True):
     def bind(ci):
         seed, qp, k = chain_list[ci]
         if ldp:
-            eng.init_chain(ci, frames[seed], fp1.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp1, ref=refs[seed])
+            kw = dict(ref=refs[seed]) if args.refs == 1 else dict(refs=pads[seed], ref_pocs=ref_pocs, poc=args.refs)
+            eng.init_chain(ci, frames[seed], fp1.qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)], params=fp1, **kw)
         else:
             eng.init_chain(ci, frames[seed], qp=qp, slice_ctus=sl if n_sl > 1 else 0, rec=recs[(seed, qp)], out=outs[(seed, qp)])
         if n_sl > 1:
@@ -303,12 +313,12 @@ def run(args, emit=True):
         per_launch = timed_ctus_gpu / max(1, args.steps)
         algo = algo_bytes_ldp(args.search_range) if ldp else ALGO_BYTES_PER_CTU
         achieved = (algo * per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        pmc = measured_counters(args.config, n_chains) if (switches is None and not args.amp and not args.shear and world == 1) else None
+        pmc = measured_counters(args.config, n_chains) if (switches is None and not args.amp and not args.shear and args.refs == 1 and world == 1) else None
         traffic = pmc["traffic_bytes_per_ctu"] * per_launch if pmc else None
         kernel_ctus_per_s = per_launch / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
-        what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture 0 of their clip; "
+        what = (f"{W}x{H} lowdelay_P QP32 (BASELINE configs[4]): P pictures referencing the deblocked, padded picture{'s' if args.refs > 1 else ' 0'} before them in their clip; "
                 f"merge + AMVP + {'TZ search (FastSearch 1)' if args.fast_search else 'full search (FastSearch 0)'} +-{args.search_range} (FEN) + half/quarter refinement (HadamardME) + inter RQT + intra fallback; "
-                f"one reference picture, TMVP off, AMP {'on' if args.amp else 'off'}{'; sheared motion (--shear 1)' if args.shear else ''}" if ldp else
+                f"{'one reference picture' if args.refs == 1 else str(args.refs) + ' reference pictures (the ' + str(args.refs) + ' pictures before it, decided untimed)'}, TMVP off, AMP {'on' if args.amp else 'off'}{'; sheared motion (--shear 1)' if args.shear else ''}" if ldp else
                 f"{W}x{H} all-intra QP{{{args.qps}}}, full depth-0..3 quadtree + chroma RDO (BASELINE configs[2])")
         res = {
             "metric": "CTUs/sec (RDO decision only) at 4K " + ("lowdelay_P" if ldp else "all-intra"), "value": value, "unit": "CTUs/sec",
@@ -347,9 +357,11 @@ def run(args, emit=True):
                 ci = chain_list.index((seeds[0], qp, 0))
                 fr = [p.cpu().numpy() for p in frames[seeds[0]]]
                 if ldp:
-                    _, q1, lam = hmo_py.ldp_slice(1, 32)
-                    mk = lambda fr=fr: hmo_py.Encoder(*fr, q1, slice_ctus=sl if n_sl > 1 else 0, ref=[p.cpu().numpy() for p in _unpad(refs[seeds[0]], W, H)],
-                                                      lambda_override=lam, search_range=args.search_range, fast_search=args.fast_search, amp=args.amp)
+                    _, q1, lam = hmo_py.ldp_slice(args.refs, 32)
+                    host_refs = [[p.cpu().numpy() for p in _unpad(t, W, H)] for t in pads[seeds[0]]]
+                    rk = dict(ref=host_refs[0]) if args.refs == 1 else dict(refs=host_refs, ref_pocs=ref_pocs, poc=args.refs)
+                    mk = lambda fr=fr: hmo_py.Encoder(*fr, q1, slice_ctus=sl if n_sl > 1 else 0, lambda_override=lam, search_range=args.search_range,
+                                                      fast_search=args.fast_search, amp=args.amp, **rk)
                 else:
                     mk = lambda fr=fr, qp=qp: hmo_py.Encoder(*fr, qp, slice_ctus=sl if n_sl > 1 else 0)
                 look = lambda a, ci=ci: eng.ctu_out(ci, a) if a < walked and switches is None else None

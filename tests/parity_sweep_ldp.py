@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle sweep of the lowdelay_P pipeline (a measurement script, not part of the test suite): short clips
 of random size (off the CTU grid), base QP, content and motion; per picture random slices, search range, TZ / full search,
-RDOQ / RDOQTS, TMVP, tool flags; decide -> deblock (random offsets) -> optional SAO -> padded reference of the next picture.
+RDOQ / RDOQTS, TMVP, tool flags, one to four reference pictures (the last n decided pictures), P pictures started from the P or
+the B context tables; decide -> deblock (random offsets) -> optional SAO -> padded reference of the next picture.
 Every fcu_ctu_out field, the reconstruction, the coder state, the deblocked and SAO-filtered planes and the signalled SAO
 parameters must be identical to the oracle's.  One line per clip and a summary; exit code 1 on any mismatch."""
 import argparse
@@ -44,7 +45,9 @@ def main():
         w, h = int(rng.integers(8, 33)) * 8, int(rng.integers(8, 21)) * 8
         base_qp = int(rng.integers(10, 45))
         gen = ["smooth", "mixed", "textured"][int(rng.integers(0, 3))]
-        n_pic = int(rng.integers(2, 5))
+        nref = int(rng.choice([1, 1, 2, 3, 4]))                 # reference pictures in list 0: the last nref decided pictures
+        n_pic = int(rng.integers(2, 5)) + (nref > 1) * int(rng.integers(1, 3))
+        btab = int(rng.random() < 0.3)                          # P pictures start from the B-slice context tables (cabac_init_flag)
         dxy = (int(rng.integers(-5, 6)), int(rng.integers(-3, 4)))
         seed = int(rng.integers(0, 10000))
         w_ctu, n_ctu = (w + 63) // 64, ((w + 63) // 64) * ((h + 63) // 64)
@@ -63,6 +66,7 @@ def main():
         eng = pkg.CuEngine(w, h, max_chains=1)
         rate_e, rate_o = pkg.engine.SaoRate(), hmo_py.SaoState()
         prev = pad = prev_out = prev_ctus = None
+        dpb = []                                                # (poc, filtered planes, padded device planes, the POCs its list 0 named)
         diffs = []
         for poc in range(n_pic):
             ox, oy = 32 + dxy[0] * poc, 32 + dxy[1] * poc
@@ -86,15 +90,28 @@ def main():
             fp.search_range, fp.fast_search, fp.rdoq, fp.rdoq_ts = sr, fast, rdoq, rdoq_ts
             fp.tmvp = 1 if (tmvp and poc) else 0
             fp.amp = amp
+            fp.cabac_b_table = 1 if (btab and poc) else 0
             for k, v in tools.items():
                 setattr(fp, k, v)
-            eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, ref=pad, col=prev_out if fp.tmvp else None)
+            rl = dpb[-nref:][::-1]
+            pocs = [r[0] for r in rl]
+            crp = (rl[0][3] or [rl[0][0] - 1]) if rl else None
+            if poc and nref > 1:
+                eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, refs=[r[2] for r in rl], ref_pocs=pocs, poc=poc, col_ref_pocs=crp, col=prev_out if fp.tmvp else None)
+            else:
+                eng.init_chain(0, f, fp.qp, slice_ctus=sl, params=fp, ref=pad, col=prev_out if fp.tmvp else None)
             eng.compress_chains(0, 1, n_ctu)
             eng.sync()
             ot = dict(tools)
             ot["strong_smoothing"] = ot.pop("strong_intra_smoothing")
             kw = dict(slice_ctus=sl, lambda_override=lam, rdoq=rdoq, rdoq_ts=rdoq_ts, **ot)
-            o = hmo_py.Encoder(*f, qp, **kw) if poc == 0 else hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, search_range=sr, fast_search=fast, amp=amp, **kw)
+            if poc == 0:
+                o = hmo_py.Encoder(*f, qp, **kw)
+            elif nref > 1:
+                o = hmo_py.Encoder(*f, qp, refs=[r[1] for r in rl], ref_pocs=pocs, poc=poc, col_ref_pocs=crp, col=prev_ctus if tmvp else None, search_range=sr,
+                                   fast_search=fast, amp=amp, cabac_b_table=btab, **kw)
+            else:
+                o = hmo_py.Encoder(*f, qp, ref=prev, col=prev_ctus if tmvp else None, search_range=sr, fast_search=fast, amp=amp, cabac_b_table=btab, **kw)
             o.compress_frame()
             for a in range(n_ctu):
                 got, want = eng.ctu_out(0, a), o.ctu_arrays(a)
@@ -129,10 +146,11 @@ def main():
                     diffs.append(f"poc{poc}.sao_planes")
             prev = rec
             pad = eng.pad_reference(eng._keep[0][1])
+            dpb.append((poc, rec, pad, pocs if poc else []))
         eng.destroy()
         bad += bool(diffs)
         print(f"clip {clip:3d} {gen:8s} {w}x{h} qp{base_qp:2d} pics {n_pic} motion {dxy} slice_ctus {sl} sr {sr} fast {fast} rdoq {rdoq}/{rdoq_ts} "
-              f"tools {list(tools.values())} sao {sao} tmvp {tmvp} amp {amp} shear {shear} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
+              f"tools {list(tools.values())} sao {sao} tmvp {tmvp} amp {amp} shear {shear} refs {nref} btab {btab} dbk {boff}/{toff}: {'OK' if not diffs else 'MISMATCH ' + ','.join(diffs[:6])}", flush=True)
     print(f"{args.clips - bad} of {args.clips} clips identical")
     sys.exit(1 if bad else 0)
 
