@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <hip/hip_runtime_api.h>
 #include "TLibEncoder/TEncTop.h"
+#include <cstring>
 #include "TLibEncoder/TEncCu.h"
 #include "fcu_marshal.h"
 
@@ -47,6 +48,20 @@ struct FcuState {
   std::vector<uint8_t> h_plane[3];
   Int poc_loaded = -1 << 30;
   fcu_ctu_out h_out;
+  /* Picture-ahead (SliceMode 1): the slices of a picture are independent chains -- nothing a slice's decisions read comes from
+   * another slice of the same picture -- so with the first CTU of the first slice all of them are bound with that slice's
+   * parameters and decided in ONE launch; compressCtu then hands out the results CTU by CTU.  A later slice whose parameters
+   * turn out to differ (a rate control that moves the QP inside the picture) is decided again on its own. */
+  /* TEncSearch::m_integerMv2Nx2N (the TZ search's carried start point) lives as long as the encoder: the adapter takes it out of
+   * the chain before it rebinds it and puts it back afterwards, so that slices and pictures run one after the other see what HM's
+   * search would.  Picture-ahead is used only where that state cannot matter: no slice may begin with a CTU too small for a
+   * 64x64 CU (such a slice's first search would read what the slice before it left). */
+  int32_t search[2 * FCU_MAX_REF] = {}; bool bound0 = false;
+  int max_chains = 0;
+  std::vector<fcu_ctu_out> h_all; std::vector<uint8_t> h_rec[3];
+  const fcu_ctu_out *last = nullptr;                           /* the record the last compressCtu marshalled (tests) */
+  int ahead_last = 0;
+  bool ahead_valid = false, serve_ahead = false; Int ahead_poc = -1 << 30; fcu_frame_params ahead_fp; int ahead_nref = 0, ahead_pocs[FCU_MAX_REF];
 };
 FcuState g_fcu;
 
@@ -55,17 +70,18 @@ void die(const char *what, int rc) { fprintf(stderr, "TEncCuFcu: %s failed (%d):
 
 size_t plane_bytes(int w, int h, int c) { return c ? (size_t)(w / 2) * (h / 2) : (size_t)w * h; }
 
-void ensure_context(const TComSPS *sps)
+void ensure_context(const TComSPS *sps, int chains)
 {
   FcuState &S = g_fcu;
   const int w = (int)sps->getPicWidthInLumaSamples(), h = (int)sps->getPicHeightInLumaSamples();
-  if (S.ctx && S.width == w && S.height == h) return;
-  if (S.ctx) {                                                 /* another picture size: start over */
+  if (S.ctx && S.width == w && S.height == h && S.max_chains >= chains) return;
+  if (S.ctx) {                                                 /* another picture size or more slices per picture: start over */
     for (int c = 0; c < 3; c++) { hipFree(S.d_org[c]); hipFree(S.d_rec[c]); hipFree(S.d_refsrc[c]); for (int k = 0; k < FcuState::N_SLOT; k++) { hipFree(S.d_ref[k][c]); S.ref_valid[k] = false; } }
-    hipFree(S.d_out); hipFree(S.d_out_prev); fcu_destroy(S.ctx); S.ctx = nullptr; S.poc_prev = S.poc_loaded = -1 << 30;
+    hipFree(S.d_out); hipFree(S.d_out_prev); fcu_destroy(S.ctx); S.ctx = nullptr; S.poc_prev = S.poc_loaded = -1 << 30; S.bound0 = false; S.ahead_valid = false;
   }
   if (sps->getChromaFormatIdc() != CHROMA_420 || sps->getBitDepth(CHANNEL_TYPE_LUMA) != 8 || sps->getMaxCUWidth() != 64) { fprintf(stderr, "TEncCuFcu: 8-bit 4:2:0 with 64x64 CTUs only\n"); exit(1); }
-  fcu_seq_params sp = { w, h, /*max_chains*/ 1, /*device*/ 0 };
+  fcu_seq_params sp = { w, h, /*max_chains*/ chains, /*device*/ 0 };
+  S.max_chains = chains; S.ahead_valid = false;
   int rc = fcu_create(&sp, &S.ctx);
   if (rc != FCU_OK) die("fcu_create", rc);
   S.width = w; S.height = h; S.n_ctu = fcu_num_ctus(S.ctx);
@@ -94,14 +110,29 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
 {
   FcuState &S = g_fcu;
   TComPic *pic = pCtu->getPic(); TComSlice *slice = pCtu->getSlice();
-  ensure_context(slice->getSPS());
+  const int nCtuPic = (int)pic->getNumberOfCtusInFrame();
+  const int sliceArg = cfg->getSliceMode() == FIXED_NUMBER_OF_CTU ? cfg->getSliceArgument() : 0;
+  int nSlices = (sliceArg > 0 && sliceArg < nCtuPic) ? (nCtuPic + sliceArg - 1) / sliceArg : 1;
+  {
+    const int wc = (int)pic->getFrameWidthInCtus(), W = (int)slice->getSPS()->getPicWidthInLumaSamples(), H = (int)slice->getSPS()->getPicHeightInLumaSamples();
+    for (int k = 0; k < nSlices && nSlices > 1; k++) {           /* picture-ahead only if every slice starts on a CTU that holds a 64x64 CU */
+      const int a = k * sliceArg, x0 = (a % wc) * 64, y0 = (a / wc) * 64;
+      if (x0 + 64 > W || y0 + 64 > H) nSlices = 1;
+    }
+    static const bool noAhead = getenv("FCU_ADAPTER_NO_AHEAD") != nullptr;     /* switch: slice by slice, as HM runs them */
+    if (noAhead) nSlices = 1;
+  }
+  if (S.ctx && S.bound0) { int r0 = fcu_chain_get_search_state(S.ctx, S.ahead_valid ? S.ahead_last : 0, S.search); if (r0 != FCU_OK) die("fcu_chain_get_search_state", r0); }
+  ensure_context(slice->getSPS(), nSlices);
+  S.serve_ahead = false;
   if (pic->getPOC() != S.poc_loaded) {                          /* once per picture: the source planes; the finished picture's decisions stay resident */
     upload(pic->getPicYuvOrg(), S.d_org);
     std::swap(S.d_out, S.d_out_prev); S.poc_prev = S.poc_loaded;
-    S.poc_loaded = pic->getPOC();
+    S.poc_loaded = pic->getPOC(); S.ahead_valid = false;
     for (int k = 0; k < FcuState::N_SLOT; k++) if (S.ref_valid[k] && S.ref_poc[k] == S.poc_loaded) S.ref_valid[k] = false;   /* a POC coded again (new IDR period) */
   }
   fcu_frame_params fp;
+  memset(&fp, 0, sizeof(fp));                                   /* (compared bytewise with the picture-ahead parameters below) */
   fcu_default_frame_params(&fp, slice->getSliceQp());
   fp.lambda = rd->getLambda(); fp.sqrt_lambda = rd->getSqrtLambda(); fp.chroma_weight = rd->getChromaWeight();   /* TEncSlice::setUpLambda */
   for (int c = 0; c < 3; c++) fp.rdoq_lambda[c] = slice->getLambdas()[c];
@@ -124,11 +155,11 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
      * previous slice (TEncSlice.cpp:1750-1753 -> TComSlice::getEncCABACTableIdx, TEncSbac::resetEntropy TEncSbac.cpp:111-115) */
     fp.cabac_b_table = (pps->getCabacInitPresentFlag() && slice->getEncCABACTableIdx() == B_SLICE) ? 1 : 0;
   }
-  int rc = fcu_chain_begin(S.ctx, 0, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
-  if (rc != FCU_OK) die("fcu_chain_begin", rc);
+  int rc = FCU_OK;
+  const int nRef = fp.slice_type == FCU_SLICE_P ? slice->getNumRefIdx(REF_PIC_LIST_0) : 0;
+  const uint8_t *planes[3 * FCU_MAX_REF]; int pocs[FCU_MAX_REF], slot[FCU_MAX_REF];
+  int colPocs[FCU_MAX_REF], nCol = 0, colPoc = 0;
   if (fp.slice_type == FCU_SLICE_P) {                           /* list 0: the filtered reconstructions HM holds */
-    const int nRef = slice->getNumRefIdx(REF_PIC_LIST_0);
-    const uint8_t *planes[3 * FCU_MAX_REF]; int pocs[FCU_MAX_REF], slot[FCU_MAX_REF];
     for (int r = 0; r < nRef; r++) {
       pocs[r] = slice->getRefPOC(REF_PIC_LIST_0, r); slot[r] = -1;
       for (int k = 0; k < FcuState::N_SLOT; k++) if (S.ref_valid[k] && S.ref_poc[k] == pocs[r]) slot[r] = k;
@@ -144,8 +175,6 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
       }
       for (int c = 0; c < 3; c++) planes[3 * r + c] = S.d_ref[slot[r]][c];
     }
-    rc = fcu_chain_set_references(S.ctx, 0, nRef, planes, pocs, slice->getPOC());
-    if (rc != FCU_OK) die("fcu_chain_set_references", rc);
     if (fp.tmvp) {
       /* collocated picture = list 0, collocated_ref_idx 0 (the encoder's choice for low-delay P): the picture coded before this
        * one, whose fcu_ctu_out array is still in HBM.  Its own list 0 gives the POCs its vectors point at; the engine scales by
@@ -155,20 +184,52 @@ void begin_slice(TComDataCU *pCtu, TComRdCost *rd, TComTrQuant *trq, TEncCfg *cf
       if (!slice->getColFromL0Flag() || slice->getColRefIdx() != 0 || col->getPOC() != S.poc_prev || (!cs->isIntra() && cs->getNumRefIdx(REF_PIC_LIST_0) > FCU_MAX_REF)) {
         fprintf(stderr, "TEncCuFcu: TMVP needs the collocated picture to be list 0 index 0 and the previously coded picture\n"); exit(1);
       }
-      rc = fcu_chain_set_collocated(S.ctx, 0, S.d_out_prev);
-      if (rc != FCU_OK) die("fcu_chain_set_collocated", rc);
-      if (!cs->isIntra()) {
-        int cp[FCU_MAX_REF]; const int n = cs->getNumRefIdx(REF_PIC_LIST_0);
-        for (int k = 0; k < n; k++) cp[k] = cs->getRefPOC(REF_PIC_LIST_0, k);
-        rc = fcu_chain_set_collocated_pocs(S.ctx, 0, col->getPOC(), cp, n);
-        if (rc != FCU_OK) die("fcu_chain_set_collocated_pocs", rc);
-      }
+      colPoc = col->getPOC();
+      if (!cs->isIntra()) { nCol = cs->getNumRefIdx(REF_PIC_LIST_0); for (int k = 0; k < nCol; k++) colPocs[k] = cs->getRefPOC(REF_PIC_LIST_0, k); }
     }
   }
-  if (fp.slice_ctus > 0) { rc = fcu_chain_set_range(S.ctx, 0, first, count); if (rc != FCU_OK) die("fcu_chain_set_range", rc); }
+  /* bind chain k to the picture with this slice's parameters, restricted to CTUs [a, a + n) (n = 0: the whole picture) */
+  auto bind_chain = [&](int k, int a, int n) {
+    int r2 = fcu_chain_begin(S.ctx, k, &fp, S.d_org[0], S.d_org[1], S.d_org[2], S.d_rec[0], S.d_rec[1], S.d_rec[2], S.d_out);
+    if (r2 != FCU_OK) die("fcu_chain_begin", r2);
+    if (fp.slice_type == FCU_SLICE_P) {
+      r2 = fcu_chain_set_references(S.ctx, k, nRef, planes, pocs, slice->getPOC());
+      if (r2 != FCU_OK) die("fcu_chain_set_references", r2);
+      if (fp.tmvp) {
+        r2 = fcu_chain_set_collocated(S.ctx, k, S.d_out_prev);
+        if (r2 != FCU_OK) die("fcu_chain_set_collocated", r2);
+        if (nCol) { r2 = fcu_chain_set_collocated_pocs(S.ctx, k, colPoc, colPocs, nCol); if (r2 != FCU_OK) die("fcu_chain_set_collocated_pocs", r2); }
+      }
+    }
+    if (n > 0) { r2 = fcu_chain_set_range(S.ctx, k, a, n); if (r2 != FCU_OK) die("fcu_chain_set_range", r2); }
+    if (k == 0) { r2 = fcu_chain_set_search_state(S.ctx, 0, S.search); if (r2 != FCU_OK) die("fcu_chain_set_search_state", r2); S.bound0 = true; }
+  };
+  auto same_lists = [&]() { if (S.ahead_nref != nRef) return false; for (int r = 0; r < nRef; r++) if (S.ahead_pocs[r] != pocs[r]) return false; return true; };
+  if (nSlices > 1) {
+    if (first == 0) {                                           /* first slice of the picture: decide all of them now */
+      for (int k = 0; k < nSlices; k++) bind_chain(k, k * sliceArg, std::min(sliceArg, nCtuPic - k * sliceArg));
+      rc = fcu_compress_chains(S.ctx, 0, nSlices, sliceArg, nullptr);
+      if (rc != FCU_OK) die("fcu_compress_chains", rc);
+      rc = fcu_sync(S.ctx);
+      if (rc != FCU_OK) die("fcu_sync", rc);
+      S.h_all.resize((size_t)nCtuPic);
+      HIPOK(hipMemcpy(S.h_all.data(), S.d_out, sizeof(fcu_ctu_out) * (size_t)nCtuPic, hipMemcpyDeviceToHost));
+      for (int c = 0; c < 3; c++) { S.h_rec[c].resize(plane_bytes(S.width, S.height, c)); HIPOK(hipMemcpy(S.h_rec[c].data(), S.d_rec[c], S.h_rec[c].size(), hipMemcpyDeviceToHost)); }
+      S.ahead_last = nSlices - 1;                               /* HM's search state after the picture is the last slice's */
+      S.ahead_valid = true; S.ahead_poc = pic->getPOC(); S.ahead_fp = fp; S.ahead_nref = nRef; for (int r = 0; r < nRef; r++) S.ahead_pocs[r] = pocs[r];
+      S.serve_ahead = true;
+      return;
+    }
+    if (S.ahead_valid && S.ahead_poc == pic->getPOC() && memcmp(&S.ahead_fp, &fp, sizeof(fp)) == 0 && same_lists()) { S.serve_ahead = true; return; }
+    S.ahead_valid = false;                                      /* this slice was given other parameters: decide it (and the rest) slice by slice */
+  }
+  bind_chain(0, first, fp.slice_ctus > 0 ? count : 0);
 }
 
 } /* namespace */
+
+/* test hook: the fcu_ctu_out record behind the CTU the last compressCtu filled, and whether it came from a picture-ahead launch */
+extern "C" int fcu_adapter_last_record(void *dst) { if (!g_fcu.last) return -1; memcpy(dst, g_fcu.last, sizeof(fcu_ctu_out)); return g_fcu.serve_ahead ? 1 : 0; }
 
 /* ---- the six public methods ------------------------------------------------------------------------------------------ */
 
@@ -202,6 +263,8 @@ Void TEncCu::destroy()
     for (int k = 0; k < FcuState::N_SLOT; k++) { hipFree(S.d_ref[k][c]); S.d_ref[k][c] = nullptr; S.ref_valid[k] = false; } }
   hipFree(S.d_out); hipFree(S.d_out_prev); S.d_out = S.d_out_prev = nullptr; S.poc_prev = -1 << 30;
   if (S.ctx) { fcu_destroy(S.ctx); S.ctx = nullptr; }
+  S.max_chains = 0; S.ahead_valid = S.serve_ahead = false; S.bound0 = false;
+  for (int k = 0; k < 2 * FCU_MAX_REF; k++) S.search[k] = 0;      /* a new encoder */
   S.width = S.height = 0; S.poc_loaded = -1 << 30;
 }
 
@@ -211,9 +274,15 @@ Void TEncCu::compressCtu(TComDataCU *pCtu)
   TComPic *pic = pCtu->getPic(); TComSlice *slice = pCtu->getSlice();
   const UInt rs = pCtu->getCtuRsAddr();
   if (rs == pic->getPicSym()->getCtuTsToRsAddrMap(slice->getSliceCurStartCtuTsAddr())) begin_slice(pCtu, m_pcRdCost, m_pcTrQuant, m_pcEncCfg);
+  const UInt wcA = pic->getFrameWidthInCtus();
+  if (S.serve_ahead) {                                          /* decided with the first slice of the picture (picture-ahead) */
+    fcu_adapter::marshal_ctu(S.h_all[rs], pCtu); S.last = &S.h_all[rs];
+    for (int c = 0; c < 3; c++) fcu_adapter::widen_ctu_block(S.h_rec[c].data(), pic->getPicYuvRec(), ComponentID(c), rs, wcA);
+    return;
+  }
   const int rc = fcu_compress_ctu(S.ctx, 0, rs, &S.h_out);      /* compressCtu + the context replay of encodeCtu, result to the host */
   if (rc != FCU_OK) die("fcu_compress_ctu", rc);
-  fcu_adapter::marshal_ctu(S.h_out, pCtu);
+  fcu_adapter::marshal_ctu(S.h_out, pCtu); S.last = &S.h_out;
   /* PicYuvRec: the CTU's block of the three planes (neighbouring CTUs and the loop filter read it on the host) */
   const UInt wc = pic->getFrameWidthInCtus();
   const int x0 = (int)(rs % wc) * 64, y0 = (int)(rs / wc) * 64;

@@ -1188,6 +1188,9 @@ template <> struct LaneVar<double> {
 __device__ inline uint32_t lane_mask16(const LaneVar<int> &f) { return (uint32_t)FCU_BALLOT(f.r != 0) & 0xffffu; }
 #endif
 
+#ifndef FCU_WAVE_RDOQ_MIN_LOG2
+#define FCU_WAVE_RDOQ_MIN_LOG2 2
+#endif
 /* The same quantiser for ONE block with the whole wave (called from wave-uniform code, not from inside a lane loop): the
  * un-split trial of a transform unit has a single candidate, and then a lane-private rdoq() leaves 63 lanes idle while one
  * lane walks every coefficient.  What is serial in xRateDistOptQuant's first loop is the order of the floating-point sums and
@@ -2037,11 +2040,13 @@ FCU_DEV FCU_NOINLINE void tu_trial(CuObj *cu, uint32_t tu_k, int comp, int cab, 
     FCU_TIC(t8_);
     const int cbfCtx = comp ? (CTX_CBF_CHROMA + tu.tr_depth) : (CTX_CBF_LUMA + (tu.tr_depth == 0 ? 1 : 0));
     const int useRdoq = FCU_UNI((int)(useTS ? P.rdoq_ts : P.rdoq));
-    if (useRdoq) rdoq_wave(cab, G->p_lscan, G->p_qscan, FCU_UNI(g_S.t_last), log2, comp, scanType, cbfCtx, P, G->r_rec, G->r_cg);
+    const int onWave = useRdoq && log2 >= FCU_WAVE_RDOQ_MIN_LOG2;      /* a 4x4 block is one group: the phases of rdoq_wave cost what its sixteen serial iterations do */
+    if (onWave) rdoq_wave(cab, G->p_lscan, G->p_qscan, FCU_UNI(g_S.t_last), log2, comp, scanType, cbfCtx, P, G->r_rec, G->r_cg);
     FCU_FOR_LANES {
       if (comp == 0) for (int i = lane; i < tu.nparts; i += 64) cu->tr_idx[part + i] = (uint8_t)tu.tr_depth;   /* setTrIdxSubParts */
       if (lane == 0) {
-        if (useRdoq) { g_S.t_abs = g_S.rw_abs; g_S.t_lsp = g_S.rw_lsp; }
+        if (onWave) { g_S.t_abs = g_S.rw_abs; g_S.t_lsp = g_S.rw_lsp; }
+        else if (useRdoq) { const RdoqOut o = rdoq<1, 1>(cab, G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, scanType, cbfCtx, P, G->r_rec, G->r_cg); g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last; }
         else { const RdoqOut o = quant_plain(G->p_lscan, G->p_qscan, 1, g_S.t_last, log2, comp, P); g_S.t_abs = o.abs_sum; g_S.t_lsp = o.last; }
         E.C->n_tu_trials++;
         FCU_COUNT(E, 15, (1ull << 40) + (unsigned long long)(g_S.t_last >= 0 ? ((g_S.t_last >> 4) + 1) * 16 : 0));   /* calls : coefficient iterations */

@@ -245,6 +245,25 @@ int fcu_chain_set_references(fcu_ctx *c, int chain, int n_ref, const uint8_t *co
   return FCU_OK;
 }
 
+int fcu_chain_get_search_state(fcu_ctx *c, int chain, int32_t *xy)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !xy) return fail(FCU_ERR_ARG, "fcu_chain_get_search_state: bad argument");
+  static_assert(sizeof(((Chain *)0)->int_mv_r) == 2 * FCU_MAX_REF * sizeof(int32_t), "search state layout");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(xy, (const char *)&c->d_chains[chain] + offsetof(Chain, int_mv_r), 2 * FCU_MAX_REF * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return FCU_OK;
+}
+int fcu_chain_set_search_state(fcu_ctx *c, int chain, const int32_t *xy)
+{
+  if (!c || chain < 0 || chain >= c->sp.max_chains || !xy) return fail(FCU_ERR_ARG, "fcu_chain_set_search_state: bad argument");
+  if (c->h_chains[(size_t)chain].out == nullptr) return fail(FCU_ERR_STATE, "fcu_chain_set_search_state: chain not bound (fcu_chain_begin)");
+  HIPCHK(hipSetDevice(c->sp.device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy((char *)&c->d_chains[chain] + offsetof(Chain, int_mv_r), xy, 2 * FCU_MAX_REF * sizeof(int32_t), hipMemcpyHostToDevice));
+  return FCU_OK;
+}
+
 int fcu_chain_set_collocated_pocs(fcu_ctx *c, int chain, int col_poc, const int *col_ref_pocs, int n)
 {
   if (!c || chain < 0 || chain >= c->sp.max_chains || !col_ref_pocs || n < 1 || n > FCU_MAX_REF) return fail(FCU_ERR_ARG, "fcu_chain_set_collocated_pocs: bad argument");

@@ -86,7 +86,7 @@ EXPORTS = ["fcu_default_frame_params", "fcu_create", "fcu_destroy", "fcu_num_ctu
            "fcu_chain_set_decision", "fcu_get_verify_counts", "fcu_decision_switch", "fcu_frame_state", "fcu_deblock",
            "fcu_build_info", "fcu_abi_sizeof", "fcu_tcm_threshold", "fcu_chain_set_reference", "fcu_pad_reference", "fcu_pad_sizes", "fcu_ldp_slice", "fcu_get_ctx_state_full",
            "fcu_sao", "fcu_sao_enabled", "fcu_sao_update_rate", "fcu_ldp_layer", "fcu_chain_set_pu_trace", "fcu_pu_index", "fcu_chain_set_collocated",
-           "fcu_chain_set_references", "fcu_chain_set_collocated_pocs"]
+           "fcu_chain_set_references", "fcu_chain_set_collocated_pocs", "fcu_chain_get_search_state", "fcu_chain_set_search_state"]
 MAX_REF = 4                                                # FCU_MAX_REF: reference pictures in list 0
 
 SLICE_I, SLICE_P = 0, 1
@@ -162,6 +162,8 @@ def load_lib():
     lib.fcu_chain_set_collocated.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.fcu_chain_set_references.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
     lib.fcu_chain_set_collocated_pocs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    lib.fcu_chain_get_search_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+    lib.fcu_chain_set_search_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -314,6 +316,17 @@ class CuEngine:
             self._chk(self.lib.fcu_chain_set_collocated(self.h, chain, col.data_ptr()), "fcu_chain_set_collocated")
             self._keep_ref[("col", chain)] = col
         return rec, out
+
+    def search_state(self, chain):
+        """m_integerMv2Nx2N of the chain: [(x, y)] per reference index (fcu_chain_get_search_state)"""
+        xy = (C.c_int32 * (2 * MAX_REF))()
+        self._chk(self.lib.fcu_chain_get_search_state(self.h, chain, xy), "fcu_chain_get_search_state")
+        return [(int(xy[2 * r]), int(xy[2 * r + 1])) for r in range(MAX_REF)]
+
+    def set_search_state(self, chain, state):
+        """after init_chain: the state the encoder's previous searches left (fcu_chain_set_search_state)"""
+        xy = (C.c_int32 * (2 * MAX_REF))(*[int(v) for p in (list(state) + [(0, 0)] * MAX_REF)[:MAX_REF] for v in p])
+        self._chk(self.lib.fcu_chain_set_search_state(self.h, chain, xy), "fcu_chain_set_search_state")
 
     def pad_reference(self, planes, stream=None):
         """(Y, U, V) device planes of a reconstructed (loop-filtered) picture -> padded planes for P chains

@@ -10,6 +10,10 @@ reference's lowdelay configuration; one batched call for all clips) -> fcu_pad_r
 Across GPUs the reference picture is the only data a rank would need from another one (one copy per picture, SURVEY.md 8e);
 with whole clips per rank there is none.
 
+TZ search state: HM's encoder carries the integer vector of its last 2Nx2N search (TEncSearch::m_integerMv2Nx2N) across slices
+and pictures.  The slice chains of this driver run side by side and start it from zero; the difference shows only for a slice
+whose first CTU is too small for a 64x64 CU (fcu_chain_get / set_search_state for callers that need HM's value).
+
 Context-table choice of a P picture (cabac_init_flag): HM initialises a P slice from the B-slice tables when
 TEncSbac::determineCabacInitIdx picked them after the previous slice (TEncSlice.cpp:1750-1753).  That choice is made on the
 BITSTREAM coder's final state, which includes the SAO syntax and a per-context "bins were coded" flag the RD path does not

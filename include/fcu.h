@@ -130,6 +130,16 @@ int  fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *dev_pad_y, co
 #define FCU_MAX_REF 4
 int  fcu_chain_set_references(fcu_ctx *c, int chain, int n_ref, const uint8_t *const *dev_pad_planes, const int *ref_pocs, int cur_poc);
 int  fcu_chain_set_collocated_pocs(fcu_ctx *c, int chain, int col_poc, const int *col_ref_pocs, int n);
+/* TEncSearch::m_integerMv2Nx2N[REF_PIC_LIST_0][r] (TEncSearch.h:123; read and written at TEncSearch.cpp:3833-3842): the integer
+ * vector of the last 2Nx2N TZ search on reference index r, an extra start point of the next search.  In HM it is a member of the
+ * encoder that is never reset: it crosses CTUs, slices and pictures.  A chain carries it from CTU to CTU and, when one chain walks
+ * several slices, from slice to slice; fcu_chain_begin starts it from zero.  A caller that runs slices or pictures one after the
+ * other as HM does (the adapter) reads it with _get after a chain's last CTU and puts it back with _set after the next
+ * fcu_chain_begin; slices decided side by side as independent chains cannot know the state the slice before them ends with and
+ * start from zero -- which differs from HM only for a slice whose first CTU is too small for a 64x64 CU (otherwise the slice's
+ * first search overwrites the state before anything reads it).  xy = { x0, y0, x1, y1, ... } for FCU_MAX_REF indices. */
+int  fcu_chain_get_search_state(fcu_ctx *c, int chain, int32_t *xy);
+int  fcu_chain_set_search_state(fcu_ctx *c, int chain, const int32_t *xy);
 /* TMVP: the motion field of the chain's reference picture = the fcu_ctu_out array that picture was decided into (device
  * pointer, fcu_num_ctus() entries, kept alive by the caller).  What TComPic::compressMotion keeps (the top-left 4x4 partition
  * of every 16x16 block) is read in place; frame_params.tmvp switches the temporal candidates on (TComDataCU.cpp:2528-2563,

@@ -123,6 +123,11 @@ typedef struct {
   unsigned lambda_motion_sad, lambda_motion_sse;   /* m_uiLambdaMotionSAD / SSE, TComRdCost.cpp:194-219 */
   int cabac_b_table;            /* P slice initialised from the B-slice context tables: TComSlice::getEncCABACTableIdx() == B_SLICE with
                                    cabac_init_present_flag (TEncSbac::resetEntropy, TEncSbac.cpp:111-115) */
+  int search_state_per_slice;   /* 0 (HM): m_integerMv2Nx2N, the TZ search's extra start point (TEncSearch.h:123, TEncSearch.cpp:3833-3842), is
+                                   encoder state that is never reset -- it crosses slices and pictures (hmo_set_int_mv carries it from
+                                   picture to picture).  1: it starts from zero with every slice, which is what a slice decided as an
+                                   independent chain next to the slices before it can know; the two differ only when a slice begins with a
+                                   CTU too small for a 64x64 CU (otherwise the first search of the slice overwrites the state unread) */
 } HmoParams;
 
 /* Per-CTU decisions, TComDataCU layout (TComDataCU.h:72-164).  One entry
@@ -196,6 +201,7 @@ typedef struct {
 } HmoPuTrace;
 void    hmo_set_col(HmoEnc *e, const HmoCtu *col);          /* decided CTUs of the reference picture (its motion field), kept alive by the caller */
 void    hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf);
+void    hmo_set_int_mv(HmoEnc *e, const int *xy);           /* ... as the encoder's previous searches left it (x, y per reference index) */
 void    hmo_test_int_mv(const HmoEnc *e, int *xy);          /* m_integerMv2Nx2N as the search holds it now (TZ search state) */
 
 /* sample adaptive offset (TEncSampleAdaptiveOffset::SAOProcess, TEncSampleAdaptiveOffset.cpp:257; TEncGOP.cpp:1434), hmo_sao.c */

@@ -16,7 +16,7 @@ class Params(C.Structure):
                 ("chroma_weight", C.c_double), ("rdoq_lambda", C.c_double * 3), ("qp_c", C.c_int),
                 ("slice_type", C.c_int), ("search_range", C.c_int), ("fast_search", C.c_int), ("fast_enc", C.c_int),
                 ("had_me", C.c_int), ("fdm", C.c_int), ("max_merge_cand", C.c_int), ("amp", C.c_int), ("tmvp", C.c_int), ("rdoq", C.c_int), ("rdoq_ts", C.c_int), ("lambda_override", C.c_double),
-                ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint), ("cabac_b_table", C.c_int)]
+                ("lambda_motion_sad", C.c_uint), ("lambda_motion_sse", C.c_uint), ("cabac_b_table", C.c_int), ("search_state_per_slice", C.c_int)]
 
 
 class Ctu(C.Structure):
@@ -233,6 +233,12 @@ class Encoder:
         v = np.zeros((4, 6), np.float64)
         self.lib.hmo_get_verify(self.h, v.ctypes.data)
         return v
+
+    def set_int_mv(self, xy):
+        """m_integerMv2Nx2N[list 0][r] as the previous picture (or whoever ran the search last) left it: [(x, y)] per reference index"""
+        a = (C.c_int * 8)(*[int(v) for p in (list(xy) + [(0, 0)] * 4)[:4] for v in p])
+        self.lib.hmo_set_int_mv.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.hmo_set_int_mv(self.h, a)
 
     def test_int_mv(self):
         xy = (C.c_int * 8)()

@@ -1062,6 +1062,7 @@ const HmoCtu *hmo_get_ctu(const HmoEnc *e, int a) { return &e->pic[a]; }
 void hmo_set_trace(HmoEnc *e, void (*fn)(void *, int, int, int), void *user) { e->trace = fn; e->trace_user = user; }
 void hmo_set_col(HmoEnc *e, const HmoCtu *col) { e->col = col; }
 void hmo_set_pu_trace(HmoEnc *e, HmoPuTrace *buf) { e->pu_trace = buf; }
+void hmo_set_int_mv(HmoEnc *e, const int *xy) { for (int r = 0; r < HMO_MAX_REF; r++) { e->int_mv_2nx2n[r].x = xy[2 * r]; e->int_mv_2nx2n[r].y = xy[2 * r + 1]; } }
 void hmo_test_int_mv(const HmoEnc *e, int *xy) { for (int r = 0; r < HMO_MAX_REF; r++) { xy[2 * r] = e->int_mv_2nx2n[r].x; xy[2 * r + 1] = e->int_mv_2nx2n[r].y; } }
 const HmoCU *hmo_test_cu(const HmoEnc *e, int d, int best) { return best ? e->best[d] : e->temp[d]; }
 const HmoYuv *hmo_test_reco(const HmoEnc *e, int d, int best) { return best ? e->reco_best[d] : e->reco_temp[d]; }
@@ -1092,6 +1093,7 @@ void hmo_compress_ctu(HmoEnc *e, int ctuRsAddr)
   int sliceEnd = sliceStart + sliceLen; if (sliceEnd > e->n_ctu) sliceEnd = e->n_ctu;
   e->cur_ctu = ctuRsAddr; e->slice_start = sliceStart;
   if (ctuRsAddr == sliceStart) hmo_cabac_init_tab(&e->slot[0][CI_CURR_BEST], e->p.qp, e->p.slice_type, e->p.cabac_b_table);     /* resetEntropy */
+  if (ctuRsAddr == sliceStart && e->p.search_state_per_slice) memset(e->int_mv_2nx2n, 0, sizeof(e->int_mv_2nx2n));
   pic_ctu_init(e, &e->pic[ctuRsAddr]);
   e->goon = e->slot[0][CI_CURR_BEST];
   e->goon_bins = 0;

@@ -74,7 +74,7 @@ objs="$objs $a"
 gcc -O2 -w -fPIC -c "$REF/Lib/libmd5/libmd5.c" -o "$OUT/obj/libmd5.o"
 g++ $FLAGS -include <(fix) -include limits -I"$HERE" -I"$ADP" -I"$HERE/../../include" -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
 cat > "$OUT/obj/export.map" <<'MAP'
-{ global: ref_*; _Z21TCMprocessOneSequencePiiS_PdS0_S0_; _Z14FindStartPointP7tBucketii; _Z17ComputeLikelyhoodiiP7tBucketi; _Z20ComputeLambdaGivenYcddd; local: *; };
+{ global: ref_*; fcu_adapter_last_record; _Z21TCMprocessOneSequencePiiS_PdS0_S0_; _Z14FindStartPointP7tBucketii; _Z17ComputeLikelyhoodiiP7tBucketi; _Z20ComputeLambdaGivenYcddd; local: *; };
 MAP
 g++ -shared -o "$OUT/libhmleaf.so" $objs "$OUT/obj/libmd5.o" "$OUT/obj/ref_driver.o" -Wl,--gc-sections -Wl,--version-script="$OUT/obj/export.map" -Wl,-z,defs \
     -L"$PKG" -lfcu -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../../fast-cu-decision-hevc_amd' -Wl,-rpath,/opt/rocm/lib

@@ -84,8 +84,10 @@ static int g_qp = 32;
 
 extern "C" {
 
+static void release_refpics(void);
 int ref_setup(int width, int height, int qp)
 {
+  release_refpics();                                 /* reference pictures of an earlier set-up may have another size */
   g_qp = qp;
   g_uiMaxCUWidth = 64; g_uiMaxCUHeight = 64; g_uiMaxCUDepth = 4; g_uiAddCUDepth = 1;
   g_bitDepth[0] = g_bitDepth[1] = 8; g_maxTrDynamicRange[0] = g_maxTrDynamicRange[1] = 15;
@@ -584,6 +586,14 @@ int ref_setup_p(const unsigned char *ry, const unsigned char *ru, const unsigned
 /* Several reference pictures: RefPicList0[k] = planes[3k..3k+2] at POC pocs[k] (k < n <= 4), the current picture at curPoc.
  * The neighbours' and the slice's reference POCs come from TComSlice::setRefPOCList, as in TEncGOP.cpp:1006. */
 static TComPic *g_refpics[4] = { 0, 0, 0, 0 };
+} /* extern "C" */
+static void release_refpics(void)
+{
+  for (int k = 1; k < 4; k++) if (g_refpics[k] && g_refpics[k] != g_refpic) { g_refpics[k]->destroy(); delete g_refpics[k]; }
+  if (g_refpic) { g_refpic->destroy(); delete g_refpic; }
+  g_refpic = 0; for (int k = 0; k < 4; k++) g_refpics[k] = 0;
+}
+extern "C" {
 int ref_setup_p_multi(int n, const unsigned char *const *planes, const int *pocs, int curPoc, double lambda)
 {
   if (!g_pic || n < 1 || n > 4) return -1;
@@ -791,11 +801,31 @@ void ref_adapter_encode_ctu(int ctu)
  * calls it (TEncSlice.cpp:1468): the members TEncCu::init takes from TEncTop are bound to this driver's objects, the slice
  * carries its lambdas (TEncSlice::setUpLambda -> TComSlice::setLambdas) and the TEncCfg the switches the adapter reads.
  * Needs a GPU (tests/test_gpu_adapter.py); the decided CTU lands in the picture's TComDataCU and PicYuvRec. */
+static int g_adapterSliceArg = 0;
+/* SliceMode 1 for the adapter runs: SliceArgument CTUs per slice (0: one slice per picture), and the slice the next CTUs belong
+ * to -- what TEncGOP's slice loop (TEncGOP.cpp:1102-1138) sets on the TComSlice before TEncSlice::compressSlice */
+void ref_adapter_slices(int arg) { g_adapterSliceArg = arg; }
+void ref_set_slice_range(int first, int count)
+{
+  if (first > 0) {                                             /* a further slice of the picture: its own TComSlice, as TEncGOP.cpp:1130-1137 makes one */
+    TComSlice *prev = g_slice;
+    g_pic->allocateNewSlice();
+    const UInt idx = g_pic->getNumAllocatedSlice() - 1;
+    g_pic->setCurrSliceIdx(idx);
+    g_slice = g_pic->getSlice(idx);
+    g_slice->copySliceInfo(prev);
+    g_slice->setSliceIdx(idx);
+  }
+  g_slice->setSliceCurStartCtuTsAddr(first); g_slice->setSliceCurEndCtuTsAddr(first + count);
+  g_slice->setSliceSegmentCurStartCtuTsAddr(first); g_slice->setSliceSegmentCurEndCtuTsAddr(first + count);
+  for (int a = first; a < first + count; a++) g_pic->getCtu(a)->initCtu(g_pic, a);      /* binds the CTUs to the current slice (TEncSlice.cpp:1395) */
+  g_ent->setEntropyCoder(g_sbac, g_slice);
+}
 int ref_adapter_compress_ctu(int ctu)
 {
   if (!g_cfg || !g_pic) return -1;
   if (!g_cuEnc) { g_cuEnc = new TEncCu(); g_cuEnc->create(4, 64, 64, CHROMA_420); }
-  g_cfg->m_sliceMode = NO_SLICES; g_cfg->m_sliceArgument = 0; g_cfg->m_useFastDecisionForMerge = true;
+  g_cfg->m_sliceMode = g_adapterSliceArg > 0 ? FIXED_NUMBER_OF_CTU : NO_SLICES; g_cfg->m_sliceArgument = g_adapterSliceArg; g_cfg->m_useFastDecisionForMerge = true;
   g_cuEnc->m_pcEncCfg = g_cfg; g_cuEnc->m_pcRdCost = g_rd; g_cuEnc->m_pcTrQuant = g_trq; g_cuEnc->m_pcEntropyCoder = g_ent;
   const double l = g_rd->getLambda(), w = g_rd->getChromaWeight();
   const double ls[3] = { l, l / w, l / w };

@@ -22,10 +22,28 @@ LEAF = os.path.join(ROOT, "oracle", "_ref", "libhmleaf.so")
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(LEAF), reason="oracle/_ref/libhmleaf.so (built where /root/reference exists) did not travel")]
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _torch_runtime_first():
+    """libhmleaf.so pulls in the system's libamdhip64 through libfcu.so; torch ships its own copy.  Whichever is loaded first serves
+    the whole process, and a process that initialised the system runtime first leaves torch without a device.  Every other GPU
+    test goes through torch, so it is made the first here as well."""
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda")
+
+
 def _ctu_through_the_adapter(R, o, a, tag):
     L = R.L
     assert L.ref_adapter_compress_ctu(a) == 0
     o.compress_ctu(a)
+    raw = C.create_string_buffer(C.sizeof(hmo_py.Ctu))
+    ahead = L.fcu_adapter_last_record(raw)
+    assert ahead >= 0
+    got = hmo_py.Ctu.from_buffer_copy(raw.raw)
+    for name, _ in hmo_py.Ctu._fields_:                         # the record itself, field by field, before it goes through the reference's coder
+        x, y = getattr(got, name), getattr(o.ctu(a), name)
+        same = (bytes(x) == bytes(y)) if hasattr(x, "_length_") else (x == y)
+        assert same, (tag, a, "fcu_ctu_out field", name, "picture-ahead" if ahead else "per CTU")
     L.ref_cabac_reset_bits()
     L.ref_adapter_encode_ctu(a)
     ctx, frac = o.cabac(full=True)
@@ -56,8 +74,39 @@ def test_intra_picture_through_compressCtu(pkg, gen, w, h, qp):
     R.L.ref_adapter_release()
 
 
-def test_lowdelay_p_clip_through_compressCtu(pkg):
-    gen, w, h, base_qp, n_pic, sr, nref = "shear_mixed", 136, 72, 30, 4, 16, 2
+@pytest.mark.parametrize("gen,w,h,qp,sl", [("textured", 200, 136, 27, 5), ("mixed", 264, 136, 32, 2)])
+def test_slices_of_a_picture_decided_ahead(pkg, gen, w, h, qp, sl):
+    """SliceMode 1: with the first CTU of the first slice the adapter binds every slice of the picture as a chain of its own,
+    decides them in one launch and then serves compressCtu from the results.  The reference's slice object is moved from
+    slice to slice as TEncGOP's slice loop does; every CTU and the picture must equal the oracle run with the same slices."""
+    f = getattr(pkg.synth, gen)(w, h, seed=6)
+    o = hmo_py.Encoder(*f, qp, slice_ctus=sl)
+    R = st.RefSearch(w, h, qp, f)
+    L = R.L
+    L.ref_cabac_frac.restype = C.c_ulonglong
+    L.ref_adapter_release()
+    L.ref_adapter_slices(sl)
+    try:
+        for first in range(0, o.n_ctu, sl):
+            n = min(sl, o.n_ctu - first)
+            L.ref_set_slice_range(first, n)
+            L.ref_cabac_reset()                                  # TEncSlice::compressSlice: resetEntropy at the start of a slice
+            for a in range(first, first + n):
+                _ctu_through_the_adapter(R, o, a, f"{gen} slice at {first}")
+        _same_reconstruction(R, o, gen)
+    finally:
+        L.ref_adapter_slices(0)
+        L.ref_adapter_release()
+
+
+@pytest.mark.parametrize("w,h,sl", [(136, 72, 0), (136, 72, 2), (192, 128, 3)])
+def test_lowdelay_p_clip_through_compressCtu(pkg, w, h, sl):
+    """sl = 0: one slice per picture.  136x72 with 2 CTUs per slice: slices begin on the 8-sample-wide CTUs of the last column, so
+    the adapter runs them one after the other and carries the TZ search state (m_integerMv2Nx2N) from slice to slice and from
+    picture to picture as HM's encoder object does.  192x128 with 3 CTUs per slice: every slice begins on a whole CTU and the
+    picture's slices are decided ahead in one launch."""
+    gen, base_qp, n_pic, sr, nref = "shear_mixed", 30, 4, 16, 2
+    search_state = [(0, 0)] * 4
     dpb = []                                                    # (poc, deblocked planes, the POCs its list 0 named)
     prev_ctus = None
     n_inter = n_far = 0
@@ -70,8 +119,9 @@ def test_lowdelay_p_clip_through_compressCtu(pkg):
             R.L.ref_adapter_release()
         L = R.L
         L.ref_cabac_frac.restype = C.c_ulonglong
+        L.ref_adapter_slices(sl)
         if poc == 0:
-            o = hmo_py.Encoder(*f, qp, lambda_override=lam)
+            o = hmo_py.Encoder(*f, qp, slice_ctus=sl, lambda_override=lam)
             L.ref_set_poc(0)
             L.ref_set_lambda.argtypes = [C.c_double]
             L.ref_set_lambda(float(lam))
@@ -80,19 +130,26 @@ def test_lowdelay_p_clip_through_compressCtu(pkg):
             rl = dpb[-nref:][::-1]
             pocs = [r[0] for r in rl]
             crp = rl[0][2] or [rl[0][0] - 1]
-            o = hmo_py.Encoder(*f, qp, refs=[r[1] for r in rl], ref_pocs=pocs, poc=poc, col=prev_ctus, col_ref_pocs=crp,
+            o = hmo_py.Encoder(*f, qp, slice_ctus=sl, refs=[r[1] for r in rl], ref_pocs=pocs, poc=poc, col=prev_ctus, col_ref_pocs=crp,
                                lambda_override=lam, search_range=sr, fast_search=1, amp=1)
+            o.set_int_mv(search_state)                          # the encoder's search state crosses pictures (TEncSearch.h:123)
             R.setup_p_multi([r[1] for r in rl], pocs, poc, lam)
             R.setup_col_multi(prev_ctus, poc, pocs[0], crp)
-        L.ref_cabac_reset()
-        for a in range(o.n_ctu):
-            _ctu_through_the_adapter(R, o, a, f"poc{poc}")
-            A = o.ctu_arrays(a)
-            n_inter += int((A["pred_mode"] == 0).sum())
-            n_far += int(((A["pred_mode"] == 0) & (A["ref_idx"] > 0)).sum())
+        for first in range(0, o.n_ctu, sl or o.n_ctu):
+            n = min(sl or o.n_ctu, o.n_ctu - first)
+            if sl:
+                L.ref_set_slice_range(first, n)
+            L.ref_cabac_reset()
+            for a in range(first, first + n):
+                _ctu_through_the_adapter(R, o, a, f"poc{poc}")
+                A = o.ctu_arrays(a)
+                n_inter += int((A["pred_mode"] == 0).sum())
+                n_far += int(((A["pred_mode"] == 0) & (A["ref_idx"] > 0)).sum())
         _same_reconstruction(R, o, f"poc{poc}")
         prev_ctus = o.all_ctus_bytes()
+        search_state = o.test_int_mv()
         o.deblock()
         dpb.append((poc, [p.copy() for p in o.rec], pocs))
     assert n_inter > 0 and n_far > 0
+    L.ref_adapter_slices(0)
     L.ref_adapter_release()

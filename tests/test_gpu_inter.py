@@ -151,6 +151,34 @@ def test_lowdelay_driver_with_the_cfg_reference_picture_sets(pkg):
     dec.close()
 
 
+def test_slice_chains_that_begin_on_partial_ctus(pkg):
+    """Slices decided side by side as independent chains start the TZ search's carried start point (m_integerMv2Nx2N) from zero;
+    HM's encoder carries it from the slice before.  The two differ only where a slice begins with a CTU too small for a 64x64 CU:
+    136x72 with two CTUs per slice puts slice starts on the 8-sample-wide last column.  The oracle follows the engine's convention
+    with search_state_per_slice = 1 (with 0 -- HM's carry -- picture 3 of this clip differs in two CTUs)."""
+    gen, w, h, base_qp, n_pic, sr, nref, sl = "shear_mixed", 136, 72, 30, 4, 16, 2, 2
+    dec = pkg.lowdelay.LowDelayPDecider(w, h, base_qp, n_clips=1, search_range=sr, slice_ctus=sl, fast_search=1, amp=True, tmvp=True, n_refs=nref, rps="recent")
+    dpb, prev_ctus = [], None
+    for poc in range(n_pic):
+        f = st.moving_frame(pkg.synth, gen, w, h, 9, poc)
+        _, qp, lam = hmo_py.ldp_slice(poc, base_qp)
+        dec.decide_picture([f])
+        if poc == 0:
+            o, pocs = hmo_py.Encoder(*f, qp, slice_ctus=sl, lambda_override=lam), []
+        else:
+            rl = dpb[-nref:][::-1]
+            pocs = [x[0] for x in rl]
+            o = hmo_py.Encoder(*f, qp, slice_ctus=sl, refs=[x[1] for x in rl], ref_pocs=pocs, poc=poc, col=prev_ctus, col_ref_pocs=rl[0][2] or [rl[0][0] - 1],
+                               lambda_override=lam, search_range=sr, fast_search=1, amp=1, search_state_per_slice=1)
+        o.compress_frame()
+        for a in range(o.n_ctu):
+            _same_ctu(dec.eng.ctu_out(0, a), o.ctu_arrays(a), f"poc{poc} ctu{a}")
+        prev_ctus = o.all_ctus_bytes()
+        o.deblock()
+        dpb.append((poc, [p.copy() for p in o.rec], pocs))
+    dec.close()
+
+
 def test_ldp_416x240_clip_matches_oracle_and_reference_loop_filter(pkg):
     """The >= 3-picture 416x240 lowdelay_P clip of the golden fixture through the batched driver (one launch per picture)."""
     import importlib.util
