@@ -138,7 +138,7 @@ def test_lowdelay_driver_with_the_cfg_reference_picture_sets(pkg):
         else:
             assert r.get("ref_pocs", rl) == rl
             ref = hmo_py.Encoder(*f, qp, slice_ctus=sl, refs=[dpb[q][0] for q in rl], ref_pocs=rl, poc=poc, col_ref_pocs=dpb[rl[0]][1] or [rl[0] - 1],
-                                 col=prev_ctus, lambda_override=lam, search_range=sr, fast_search=1, amp=1)
+                                 col=prev_ctus, lambda_override=lam, search_range=sr, fast_search=1, amp=1, search_state_per_slice=1)
         ref.compress_frame()
         for a in range(ref.n_ctu):
             _same_ctu(dec.eng.ctu_out(0, a), ref.ctu_arrays(a), f"poc{poc} ctu{a}")
@@ -227,7 +227,8 @@ def test_4k_pair_ctu_rows(pkg, gen, fast, amp, rows, sr, tmvp):
     r1 = dec.decide_picture([f1])[0]
     _, qp, lam = hmo_py.ldp_slice(1, base_qp)
     col = bytes(r0["out"].cpu().numpy()) if tmvp else None
-    ref = hmo_py.Encoder(*f1, qp, slice_ctus=sl, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp)
+    ref = hmo_py.Encoder(*f1, qp, slice_ctus=sl, ref=prev, col=col, lambda_override=lam, search_range=sr, fast_search=fast, amp=amp,
+                         search_state_per_slice=1)           # the rows are slice chains decided side by side (the bottom row begins on 48-sample-high CTUs)
     n_inter = 0
     for row in rows:
         for a in range(row * 60, row * 60 + 60):
