@@ -1369,13 +1369,18 @@ FCU_DEV FCU_NOINLINE void rdoq_wave(int c, const int32_t *src, int16_t *dst, int
         }
       } else cgflag |= 1ull << cgBlk;
     }
-    FCU_FOR_LANES {                                            /* records and levels of the group to the pools */
+    /* records and levels of the group to the pools.  The passes that follow read the records of groups that kept a level only
+     * (last position: flagged groups; sign hiding: groups with two levels four positions apart): a group without one stores
+     * its sixteen zero levels and nothing else */
+    const int keepsLevel = (int)((cgflag >> cgBlk) & 1);
+    FCU_FOR_LANES {
       if (lane < 16) {
         const int sp = cgScanPos * 16 + lane;
-        RdoqRec r; r.cc = vCc.own(lane); r.cs = vCs.own(lane); r.c0 = vC0.own(lane); r.up = vUp.own(lane); r.dn = vDn.own(lane); r.sd = vSd.own(lane); r.du = vDu.own(lane);
-        int lv = vLv.own(lane);
-        if (zeroed && lv) { lv = 0; r.cc = r.c0; r.cs = 0; }
-        recg[sp] = r; dstg[sp] = (int16_t)lv;
+        if (keepsLevel) {
+          RdoqRec r; r.cc = vCc.own(lane); r.cs = vCs.own(lane); r.c0 = vC0.own(lane); r.up = vUp.own(lane); r.dn = vDn.own(lane); r.sd = vSd.own(lane); r.du = vDu.own(lane);
+          recg[sp] = r;
+        }
+        dstg[sp] = (int16_t)(zeroed ? 0 : vLv.own(lane));
       }
       if (lane == 0) cgg[cgScanPos] = cgSig;
     }
