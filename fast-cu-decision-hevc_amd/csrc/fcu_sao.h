@@ -200,7 +200,9 @@ static_assert(sizeof(SaoCand) == 32 && sizeof(SaoPar) == 8 && sizeof(fcu_sao_ctu
 enum { SAO_NL = 64 };
 #else
 #define SAO_PHASE for (int lane = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
-#define SAO_SYNC() __syncthreads()
+/* one wave per workgroup: LDS accesses of a wave execute in program order, so the hand-over between its lanes needs no
+ * barrier -- and must not get __syncthreads()' memory fence, which would wait for the statistics prefetch in flight */
+#define SAO_SYNC() __builtin_amdgcn_wave_barrier()
 #define SAO_L 0
 enum { SAO_NL = 1 };
 #endif
