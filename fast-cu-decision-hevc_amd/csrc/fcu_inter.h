@@ -1,8 +1,8 @@
 /*
  * fcu_inter.h -- the P-slice half of the CTU engine (BASELINE configs[4]); included by fcu_engine.h inside namespace fcu.
  *
- * Configuration built: one reference picture (list 0 = the previous picture after the loop filters,
- * padded planes), TMVP and AMP optional (frame parameters), TZ search (FastSearch 1) or full integer search with FEN
+ * Configuration built: one to four reference pictures in list 0 (padded planes of pictures after the loop
+ * filters, with their POCs: reference-index loop and syntax, POC-scaled predictors), TMVP and AMP optional (frame parameters), TZ search (FastSearch 1) or full integer search with FEN
  * sub-sampling, half / quarter refinement on Hadamard cost, FDM, MaxNumMergeCand 5, QuadtreeTUMaxDepthInter 3.  The inter
  * candidates of a CU that predict the same block share one residual coding (Scratch::memo_*).  Replaces, per routine
  * (paths in the reference):
@@ -88,8 +88,8 @@ FCU_DEV int same_motion(const Nb &a, const Nb &b) { return a.mvx == b.mvx && a.m
 /* getInterMergeCandidates (P slice, no TMVP) -> g_S.mrg_mv / mrg_ref; one lane */
 /* ---- TMVP: the reference picture is the collocated picture (collocated_from_l0, collocated_ref_idx 0).  xGetColMVP
  * (TComDataCU.cpp:3175-3242): the motion its fcu_ctu_out array holds at the top-left 4x4 partition of the 16x16 block that
- * contains the position (what TComPic::compressMotion keeps); unavailable where that partition is intra.  One reference,
- * consecutive pictures: both POC distances are 1, no scaling. */
+ * contains the position (what TComPic::compressMotion keeps); unavailable where that partition is intra.  The vector is
+ * scaled when the two POC distances differ (col_mvp below). */
 /* xGetDistScaleFactor (TComDataCU.cpp:3312-3329) and TComMv::scaleMv (TComMv.h:145-150): vectors of neighbours / of the
  * collocated picture that point at another reference picture are scaled by the ratio of the POC distances */
 FCU_DEV int dist_scale(int curPoc, int curRefPoc, int colPoc, int colRefPoc)
@@ -622,7 +622,7 @@ FCU_DEV FCU_NOINLINE void motion_estimation(const CuObj *cu, int ps, int pu, int
   FCU_SERIAL { g_S.me_out[0] = mvx; g_S.me_out[1] = mvy; g_S.acc[12] = bits; g_S.acc[13] = cost; }
 }
 
-/* ---- predInterSearch (P slice, one reference picture): motion of every PU of the CU + its prediction in predt[d] */
+/* ---- predInterSearch (P slice, list 0 with 1..4 reference pictures): motion of every PU of the CU + its prediction in predt[d] */
 FCU_DEV FCU_NOINLINE void pred_inter_search(CuObj *cu, int ps, int useMrg)
 {
   const Env E = env_get(); cu = FCU_UNI(cu); ps = FCU_UNI(ps); useMrg = FCU_UNI(useMrg);

@@ -216,7 +216,7 @@ int fcu_chain_set_reference(fcu_ctx *c, int chain, const uint8_t *py, const uint
   h.ref_stride[0] = sy; h.ref_stride[1] = h.ref_stride[2] = sc;
   h.ref[0] = py + (size_t)m * sy + m; h.ref[1] = pu + (size_t)(m / 2) * sc + m / 2; h.ref[2] = pv + (size_t)(m / 2) * sc + m / 2;
   static_assert(offsetof(Chain, ref_stride) == offsetof(Chain, ref) + 3 * sizeof(void *), "ref / ref_stride are adjacent");
-  /* one reference picture at POC distance 1 (no vector is ever scaled): list 0 = { this picture } */
+  /* this entry point: one reference picture at POC distance 1 (no vector is ever scaled), list 0 = { this picture } */
   for (int k = 0; k < 3; k++) h.refs[0][k] = h.ref[k];
   h.n_ref = 1; h.poc = 1; h.ref_poc[0] = 0; h.col_poc = 0; h.col_ref_poc[0] = -1;
   HIPCHK(hipDeviceSynchronize());

@@ -2,9 +2,9 @@
  * hmo_inter.h -- ORACLE (test infrastructure).  The P-slice half of the CU decision loop (BASELINE configs[4]), an
  * implementation include of hmo_search.c (it shares that file's static helpers).
  *
- * Restates, for the configuration written down in DESIGN.md 3e (one reference picture = the previous reconstructed
- * picture, list 0 only, TMVP off, AMP off, FastSearch 0 = full integer search, FEN, FDM, HadamardME, no weighted
- * prediction, MaxNumMergeCand 5, Log2ParMrgLevel 2, QuadtreeTUMaxDepthInter 3):
+ * Restates, for the configuration written down in DESIGN.md 3e (list 0 only with one to four reference pictures, TMVP and AMP
+ * optional, full integer search or TZ search, FEN, FDM, HadamardME, no weighted prediction, MaxNumMergeCand 5,
+ * Log2ParMrgLevel 2, QuadtreeTUMaxDepthInter 3):
  *   TEncCu::xCheckRDCostMerge2Nx2N (TEncCu.cpp:1900-2018), xCheckRDCostInter (:2025-2062),
  *   TEncSearch::predInterSearch (TEncSearch.cpp:3008-3506), xEstimateMvPredAMVP (:3513-3575), xGetTemplateCost (:3715-3757),
  *   xMotionEstimation (:3764-3860), xSetSearchRange (:3865-3882), xPatternSearch (:3886-3942), xPatternSearchFracDIF
@@ -80,10 +80,10 @@ static HmoNb nb_motion(const HmoEnc *e, const HmoCU *cu, int nx, int ny, int cx,
 static int same_motion(const HmoNb *a, const HmoNb *b) { return a->mv.x == b->mv.x && a->mv.y == b->mv.y && a->ref == b->ref; }   /* hasEqualMotion, list 0 */
 
 /* getInterMergeCandidates for a P slice without TMVP: spatial A1, B1, B0, A0, B2, then zero candidates (refIdx 0) */
-/* ---- temporal motion vector prediction (TMVP), one reference picture = the collocated picture (collocated_from_l0,
+/* ---- temporal motion vector prediction (TMVP), collocated picture = list 0 index 0 (collocated_from_l0,
  * collocated_ref_idx 0).  xGetColMVP, TComDataCU.cpp:3175-3242: the motion the collocated picture holds at a position after
  * TComPic::compressMotion (the top-left 4x4 partition of every 16x16 block stands for the block); not available where that
- * partition is intra.  With consecutive pictures and one reference both POC distances are 1: no scaling (iScale == 4096). */
+ * partition is intra.  Scaled by the two POC distances when they differ (iScale != 4096). */
 /* xGetDistScaleFactor, TComDataCU.cpp:3312-3329, and TComMv::scaleMv, TComMv.h:145-150 */
 static int dist_scale(int curPoc, int curRefPoc, int colPoc, int colRefPoc)
 {
@@ -499,7 +499,7 @@ static uint32_t inter_pred_error(HmoEnc *e, const HmoCU *cu, int partSize, int p
   return e->p.had_me ? hmo_satd(org, 64, p, 64, w, h) : sad_blocks(org, 64, p, 64, w, h);
 }
 
-/* predInterSearch for a P slice with one reference picture */
+/* predInterSearch for a P slice: loop over the reference indices of list 0 */
 static void pred_inter_search(HmoEnc *e, HmoCU *cu, int partSize, int useMrg)
 {
   const int d = cu->depth_cu, npu = pu_count(partSize);
