@@ -7,13 +7,14 @@
  * Four launches per batch of pictures; everything but the third is data parallel:
  *   sao_stats    one workgroup per (CTU, component, picture): getBlkStats (:922-1381) -- every sample is classified for the
  *                four edge directions and the band table, (org - src) and 1 accumulate in an LDS histogram (integer LDS
- *                atomics: order-free, so the sums are exact whatever the interleaving).  HBM-bound: reads org + src once
- *                (the 3x3 neighbourhood comes from L2), writes 1 280 B per block.
+ *                atomics: order-free, so the sums are exact whatever the interleaving).  Reads org + src once (the 3x3
+ *                neighbourhood comes from L2), writes 1 280 B per block; bound by the LDS atomics (up to ten per sample, most
+ *                on the flat class of one address): 130-140 GB/s measured.
  *   sao_cands    one thread per (CTU, component, type, picture): deriveOffsets / estIterOffset (:441-591) and the
  *                distortion of the derived offsets (:397-433) -- they depend on the statistics and lambda only.
- *   sao_decide   one thread per picture, CTUs in coding order: what is left of decideBlkParams (:790-920) is the rate of
+ *   sao_decide   one wave per picture, CTUs in coding order: what is left of decideBlkParams (:790-920) is the rate of
  *                each candidate on the CABAC bit counter (two adaptive contexts carried from CTU to CTU), the new / merge
- *                choice, and the reconstruction of merged parameters.
+ *                choice, and the reconstruction of merged parameters (see sao_decide_picture below).
  *   sao_apply    one workgroup per (CTU, component, picture): offsetBlock (:317-556) from the untouched copy of the
  *                deblocked picture into the reconstruction.  HBM-bound: reads src, writes rec.
  * 8-bit 4:2:0, 64x64 CTUs, LFCrossSliceBoundaryFlag 1, no tiles: neighbour availability is the picture boundary
