@@ -8,8 +8,8 @@
  *   sao_stats    one workgroup per (CTU, component, picture): getBlkStats (:922-1381) -- every sample is classified for the
  *                four edge directions and the band table, (org - src) and 1 accumulate in an LDS histogram (integer LDS
  *                atomics: order-free, so the sums are exact whatever the interleaving).  Reads org + src once (the 3x3
- *                neighbourhood comes from L2), writes 1 280 B per block; bound by the LDS atomics (up to ten per sample, most
- *                on the flat class of one address): 130-140 GB/s measured.
+ *                neighbourhood comes from L2), writes 1 280 B per block.  Band statistics by LDS atomics, edge statistics in
+ *                registers with one wave reduction per class.
  *   sao_cands    one thread per (CTU, component, type, picture): deriveOffsets / estIterOffset (:441-591) and the
  *                distortion of the derived offsets (:397-433) -- they depend on the statistics and lambda only.
  *   sao_decide   one wave per picture, CTUs in coding order: what is left of decideBlkParams (:790-920) is the rate of
@@ -52,18 +52,37 @@ __device__ static inline void sao_stats_phase(int32_t *hist, const SaoPic *pics,
   const int eyFull = B ? bh - skipB : bh, ey = B ? bh - skipB : bh - 1;
   const size_t o0 = (size_t)(y0 >> sh) * stride + (x0 >> sh);
   const uint8_t *src = P.src[comp] + o0, *org = P.org[comp] + o0;
+  /* The five classes of the four edge directions are summed per thread in registers (compare-selects, no addressing) and reduced
+   * once per wave: most samples of a picture fall into the flat class, and sixty-four lanes adding to one LDS word serialise.
+   * The 32 bands spread over their addresses and keep the LDS atomic. */
+  int32_t ed[4][5], ec[4][5];
+#pragma unroll
+  for (int ty = 0; ty < 4; ty++)
+#pragma unroll
+    for (int q = 0; q < 5; q++) { ed[ty][q] = 0; ec[ty][q] = 0; }
   for (int i = t; i < bw * bh; i += SAO_THREADS) {
     const int y = i / bw, x = i - y * bw;
     const uint8_t *s = src + (size_t)y * stride + x;
     const int c = s[0], d = (int)org[(size_t)y * stride + x] - c;
-#define SAO_ADD(type, k) do { atomicAdd(&hist[((type) * 2) * 32 + (k)], d); atomicAdd(&hist[((type) * 2 + 1) * 32 + (k)], 1); } while (0)
-    if (x < exFull && y < eyFull) SAO_ADD(SAO_BO, c >> 3);
-    if (x >= sx && x < ex && y < eyFull) SAO_ADD(0, 2 + sao_sgn(c - s[-1]) + sao_sgn(c - s[1]));
-    if (x < exFull && y >= (A ? 0 : 1) && y < ey) SAO_ADD(1, 2 + sao_sgn(c - s[-stride]) + sao_sgn(c - s[stride]));
-    if (y == 0 ? (A && x >= (AL ? 0 : 1) && x < ex) : (y < ey && x >= sx && x < ex)) SAO_ADD(2, 2 + sao_sgn(c - s[-stride - 1]) + sao_sgn(c - s[stride + 1]));
-    if (y == 0 ? (A && x >= sx && x < ex) : (y < ey && x >= sx && x < ex)) SAO_ADD(3, 2 + sao_sgn(c - s[-stride + 1]) + sao_sgn(c - s[stride - 1]));
-#undef SAO_ADD
+#define SAO_EDGE(type, k) do { const int k_ = (k); _Pragma("unroll") for (int q = 0; q < 5; q++) { const int m_ = k_ == q; ed[type][q] += m_ ? d : 0; ec[type][q] += m_; } } while (0)
+    if (x < exFull && y < eyFull) { atomicAdd(&hist[(SAO_BO * 2) * 32 + (c >> 3)], d); atomicAdd(&hist[(SAO_BO * 2 + 1) * 32 + (c >> 3)], 1); }
+    if (x >= sx && x < ex && y < eyFull) SAO_EDGE(0, 2 + sao_sgn(c - s[-1]) + sao_sgn(c - s[1]));
+    if (x < exFull && y >= (A ? 0 : 1) && y < ey) SAO_EDGE(1, 2 + sao_sgn(c - s[-stride]) + sao_sgn(c - s[stride]));
+    if (y == 0 ? (A && x >= (AL ? 0 : 1) && x < ex) : (y < ey && x >= sx && x < ex)) SAO_EDGE(2, 2 + sao_sgn(c - s[-stride - 1]) + sao_sgn(c - s[stride + 1]));
+    if (y == 0 ? (A && x >= sx && x < ex) : (y < ey && x >= sx && x < ex)) SAO_EDGE(3, 2 + sao_sgn(c - s[-stride + 1]) + sao_sgn(c - s[stride - 1]));
+#undef SAO_EDGE
   }
+#pragma unroll
+  for (int ty = 0; ty < 4; ty++)
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+#ifdef FCU_EMU
+      hist[(ty * 2) * 32 + q] += ed[ty][q]; hist[(ty * 2 + 1) * 32 + q] += ec[ty][q];
+#else
+      const uint32_t sd = fcu_wave_sum((uint32_t)ed[ty][q]), sc = fcu_wave_sum((uint32_t)ec[ty][q]);      /* (two's complement: the signed sum) */
+      if ((t & 63) == 0) { atomicAdd(&hist[(ty * 2) * 32 + q], (int32_t)sd); atomicAdd(&hist[(ty * 2 + 1) * 32 + q], (int32_t)sc); }
+#endif
+    }
 }
 
 /* ---- offsets of one (CTU, component, type) ------------------------------------------------------------------------- */
